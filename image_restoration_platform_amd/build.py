@@ -1,0 +1,80 @@
+"""In-tree build of libire.so with hipcc for gfx950 (no cmake/ninja; seconds per file).
+
+`python -m image_restoration_platform_amd.build` or `__graft_entry__.build()`.
+The .so stays in-tree (git-ignored) so it travels to the GPU box with the snapshot.
+"""
+import concurrent.futures
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "lib", "libire.so")
+
+# (source, extra flags).  classifier.hip carries the IEEE-exact double finalize: no FMA contraction.
+SOURCES = [
+    ("classifier.hip", ["-ffp-contract=off"]),
+    ("conv_mfma.hip", []),
+    ("gn.hip", []),
+    ("fusion.hip", []),
+    ("engine.cpp", []),
+    ("api.cpp", []),
+]
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+          "-D__HIP_PLATFORM_AMD__"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _deps_mtime():
+    m = 0.0
+    for root, _, files in os.walk(CSRC):
+        for f in files:
+            if f.endswith((".hpp", ".inc", ".h")):
+                m = max(m, os.path.getmtime(os.path.join(root, f)))
+    m = max(m, os.path.getmtime(os.path.join(HERE, "..", "include", "ire.h")))
+    return m
+
+
+def _compile(src, extra, force, hdr_m):
+    path = os.path.join(CSRC, src)
+    obj = os.path.join(OBJ, src.replace(".", "_") + ".o")
+    if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(path)
+            and os.path.getmtime(obj) > hdr_m):
+        return obj
+    lang = ["-x", "hip"] if src.endswith((".hip", ".cpp")) else []
+    cmd = [_hipcc()] + COMMON + extra + lang + ["-c", path, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
+    return obj
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    srcs = [(s, f) for s, f in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    if os.path.exists(os.path.join(CSRC, "fusion_stub.cpp")) and not os.path.exists(os.path.join(CSRC, "fusion.hip")):
+        srcs.append(("fusion_stub.cpp", []))
+    hdr_m = _deps_mtime()
+    with concurrent.futures.ThreadPoolExecutor(max_workers=6) as ex:
+        objs = list(ex.map(lambda sf: _compile(sf[0], sf[1], force, hdr_m), srcs))
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    if verbose:
+        print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,322 @@
+// api.cpp -- the C ABI of libire.so (include/ire.h): argument checks, exception -> status
+// translation, thread-local error text, and the async batcher behind ire_submit/ire_poll.
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <thread>
+
+#include "engine.hpp"
+#include "fusion.hpp"
+
+namespace ire {
+
+static thread_local std::string g_last_error;
+void set_last_error(int code, const std::string& msg) { (void)code; g_last_error = msg; }
+
+// ---- async batcher: restoreBatch's in-flight promises (restorator.js:181-236) coalesced into
+// engine batches of up to max_batch equal-shape images.
+struct Job {
+    int h, w, is_jpeg;
+    std::vector<uint8_t> in, out;
+    double scores[7];
+    ire_timings t{};
+    int status = -1;  // -1 pending, else ire_status
+    std::string err;
+};
+
+}  // namespace ire
+
+struct ire_job { std::shared_ptr<ire::Job> j; };
+
+struct ire_engine {
+    std::unique_ptr<ire::Engine> eng;
+    // batcher
+    std::mutex qmu;
+    std::condition_variable qcv, dcv;
+    std::deque<std::shared_ptr<ire::Job>> queue;
+    std::thread worker;
+    bool stop = false;
+    int device = 0;
+    ~ire_engine() {
+        {
+            std::lock_guard<std::mutex> lk(qmu);
+            stop = true;
+        }
+        qcv.notify_all();
+        if (worker.joinable()) worker.join();
+    }
+};
+
+namespace ire {
+
+static void batcher_loop(ire_engine* E) {
+    (void)hipSetDevice(E->device);
+    for (;;) {
+        std::vector<std::shared_ptr<Job>> batch;
+        {
+            std::unique_lock<std::mutex> lk(E->qmu);
+            E->qcv.wait(lk, [&] { return E->stop || !E->queue.empty(); });
+            if (E->stop && E->queue.empty()) return;
+            // small coalescing window: more submissions of the same shape usually follow at once
+            if ((int)E->queue.size() < E->eng->max_batch()) {
+                E->qcv.wait_for(lk, std::chrono::microseconds(200),
+                                [&] { return E->stop || (int)E->queue.size() >= E->eng->max_batch(); });
+            }
+            const int h = E->queue.front()->h, w = E->queue.front()->w;
+            for (auto it = E->queue.begin(); it != E->queue.end() && (int)batch.size() < E->eng->max_batch();) {
+                if ((*it)->h == h && (*it)->w == w) { batch.push_back(*it); it = E->queue.erase(it); }
+                else ++it;
+            }
+        }
+        const int n = (int)batch.size(), h = batch[0]->h, w = batch[0]->w;
+        const size_t ib = (size_t)h * w * 3;
+        std::vector<uint8_t> in(ib * n), out(ib * n), jp(n);
+        std::vector<double> sc(7 * (size_t)n);
+        for (int i = 0; i < n; ++i) { std::memcpy(in.data() + ib * i, batch[i]->in.data(), ib); jp[i] = (uint8_t)batch[i]->is_jpeg; }
+        int status = IRE_OK;
+        std::string err;
+        ire_timings t{};
+        try {
+            std::lock_guard<std::mutex> lk(E->eng->mutex());
+            E->eng->classify_host(in.data(), n, h, w, 3 * w, jp.data(), sc.data(), nullptr);
+            E->eng->restore_host(in.data(), n, h, w, sc.data(), jp.data(), out.data(), &t);
+        } catch (const Error& e) { status = e.code; err = e.msg; }
+        catch (const std::exception& e) { status = IRE_ERR_INTERNAL; err = std::string("internal: ") + e.what(); }
+        {
+            std::lock_guard<std::mutex> lk(E->qmu);
+            for (int i = 0; i < n; ++i) {
+                Job& j = *batch[i];
+                if (status == IRE_OK) {
+                    j.out.assign(out.begin() + ib * i, out.begin() + ib * (i + 1));
+                    std::memcpy(j.scores, sc.data() + 7 * i, sizeof(double) * 7);
+                    j.t = t;
+                }
+                j.err = err;
+                j.status = status;
+                j.in.clear(); j.in.shrink_to_fit();
+            }
+        }
+        E->dcv.notify_all();
+    }
+}
+
+template <typename F>
+static int guarded(F&& f) {
+    try {
+        f();
+        return IRE_OK;
+    } catch (const Error& e) {
+        set_last_error(e.code, e.msg);
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        set_last_error(IRE_ERR_UNAVAILABLE, "service unavailable: out of host memory");
+        return IRE_ERR_UNAVAILABLE;
+    } catch (const std::exception& e) {
+        set_last_error(IRE_ERR_INTERNAL, std::string("internal: ") + e.what());
+        return IRE_ERR_INTERNAL;
+    }
+}
+
+static Engine& eng(ire_engine* e) {
+    if (!e || !e->eng) fail(IRE_ERR_INVALID_INPUT, "invalid engine handle");
+    return *e->eng;
+}
+
+static int family_id(const char* f) {
+    if (!f) fail(IRE_ERR_INVALID_INPUT, "invalid family");
+    const char* names[] = {"classifier", "conv3x3", "conv1x1", "stem", "head", "gn_finalize", "fusion"};
+    for (int i = 0; i < 7; ++i) if (!std::strcmp(f, names[i])) return i;
+    if (!std::strcmp(f, "all")) return -1;
+    fail(IRE_ERR_INVALID_INPUT, "invalid family name");
+}
+
+}  // namespace ire
+
+using namespace ire;
+
+extern "C" {
+
+int ire_abi_version(void) { return IRE_ABI_VERSION; }
+
+const char* ire_last_error(void) { return g_last_error.c_str(); }
+
+int ire_init(const ire_config* cfg, ire_engine** out) {
+    return guarded([&] {
+        if (!cfg || !out) fail(IRE_ERR_INVALID_INPUT, "invalid arguments to ire_init");
+        if (cfg->struct_size < sizeof(ire_config)) fail(IRE_ERR_INVALID_INPUT, "invalid ire_config.struct_size");
+        *out = nullptr;
+        std::unique_ptr<ire_engine> E(new ire_engine());
+        E->eng.reset(new Engine(*cfg));
+        E->device = cfg->device_index;
+        *out = E.release();
+    });
+}
+
+void ire_shutdown(ire_engine* e) { delete e; }
+
+int ire_load_weights(ire_engine* e, const void* blob, size_t bytes) {
+    return guarded([&] {
+        Engine& E = eng(e);
+        if (!blob) fail(IRE_ERR_INVALID_INPUT, "invalid weight blob");
+        std::lock_guard<std::mutex> lk(E.mutex());
+        E.load_weights(blob, bytes);
+    });
+}
+
+int ire_max_batch_for(ire_engine* e, int h, int w) {
+    if (!e || !e->eng || h <= 0 || w <= 0 || h > 8192 || w > 8192) return 0;
+    return e->eng->max_batch();
+}
+
+int ire_classify(ire_engine* e, const uint8_t* rgb, int n, int h, int w, int row_stride, const uint8_t* is_jpeg,
+                 double* scores_out, int32_t* label_out) {
+    return guarded([&] {
+        Engine& E = eng(e);
+        std::lock_guard<std::mutex> lk(E.mutex());
+        E.classify_host(rgb, n, h, w, row_stride, is_jpeg, scores_out, label_out);
+    });
+}
+
+int ire_restore(ire_engine* e, const uint8_t* rgb, int n, int h, int w, const double* scores, const uint8_t* is_jpeg,
+                uint8_t* out_rgb, ire_timings* t) {
+    return guarded([&] {
+        Engine& E = eng(e);
+        std::lock_guard<std::mutex> lk(E.mutex());
+        E.restore_host(rgb, n, h, w, scores, is_jpeg, out_rgb, t);
+    });
+}
+
+int ire_fuse(ire_engine* e, const uint8_t* rgb_views, int k, int h, int w, double noise_score, uint8_t* out_rgb,
+             int32_t* shifts_out, ire_timings* t) {
+    return guarded([&] {
+        Engine& E = eng(e);
+        std::lock_guard<std::mutex> lk(E.mutex());
+        fuse_host(E, rgb_views, k, h, w, noise_score, out_rgb, shifts_out, t);
+    });
+}
+
+int ire_classify_device(ire_engine* e, const uint8_t* d_rgb, int n, int h, int w, const uint8_t* d_is_jpeg,
+                        double* d_scores, int32_t* d_label, void* stream) {
+    return guarded([&] {
+        Engine& E = eng(e);
+        std::lock_guard<std::mutex> lk(E.mutex());
+        E.classify_device(d_rgb, n, h, w, d_is_jpeg, d_scores, d_label, (hipStream_t)stream);
+    });
+}
+
+int ire_restore_device(ire_engine* e, const uint8_t* d_rgb, int n, int h, int w, const double* d_scores,
+                       const uint8_t* d_is_jpeg, uint8_t* d_out_rgb, void* stream) {
+    return guarded([&] {
+        Engine& E = eng(e);
+        std::lock_guard<std::mutex> lk(E.mutex());
+        E.restore_device(d_rgb, n, h, w, d_scores, d_is_jpeg, d_out_rgb, (hipStream_t)stream);
+    });
+}
+
+int ire_fuse_device(ire_engine* e, const uint8_t* d_rgb_views, int k, int h, int w, double noise_score,
+                    uint8_t* d_out_rgb, int32_t* d_shifts, void* stream) {
+    return guarded([&] {
+        Engine& E = eng(e);
+        std::lock_guard<std::mutex> lk(E.mutex());
+        fuse_device(E, d_rgb_views, k, h, w, noise_score, d_out_rgb, d_shifts, (hipStream_t)stream);
+    });
+}
+
+int ire_submit(ire_engine* e, const uint8_t* rgb, int h, int w, int is_jpeg, ire_job** job_out) {
+    return guarded([&] {
+        eng(e);
+        if (!rgb || !job_out) fail(IRE_ERR_INVALID_INPUT, "invalid arguments to ire_submit");
+        if (h <= 0 || w <= 0 || h % 8 || w % 8 || h < 16 || w < 16 || h > 8192 || w > 8192)
+            fail(IRE_ERR_INVALID_INPUT, "invalid image size for restore: height and width must be multiples of 8, >= 16");
+        auto j = std::make_shared<Job>();
+        j->h = h; j->w = w; j->is_jpeg = is_jpeg ? 1 : 0;
+        j->in.assign(rgb, rgb + (size_t)h * w * 3);
+        {
+            std::lock_guard<std::mutex> lk(e->qmu);
+            if (!e->worker.joinable()) e->worker = std::thread(batcher_loop, e);
+            e->queue.push_back(j);
+        }
+        e->qcv.notify_all();
+        *job_out = new ire_job{j};
+    });
+}
+
+int ire_poll(ire_engine* e, ire_job* job, int timeout_ms, uint8_t* out_rgb, double* scores_out, ire_timings* t) {
+    return guarded([&] {
+        eng(e);
+        if (!job || !job->j) fail(IRE_ERR_INVALID_INPUT, "invalid job handle");
+        std::shared_ptr<Job> j = job->j;
+        {
+            std::unique_lock<std::mutex> lk(e->qmu);
+            auto done = [&] { return j->status >= 0; };
+            if (timeout_ms < 0) e->dcv.wait(lk, done);
+            else if (!e->dcv.wait_for(lk, std::chrono::milliseconds(timeout_ms), done))
+                fail(IRE_ERR_TIMEOUT, "timeout: job still pending");
+        }
+        const int st = j->status;
+        const std::string err = j->err;
+        if (st == IRE_OK) {
+            if (out_rgb) std::memcpy(out_rgb, j->out.data(), j->out.size());
+            if (scores_out) std::memcpy(scores_out, j->scores, sizeof(double) * 7);
+            if (t) *t = j->t;
+        }
+        delete job;
+        if (st != IRE_OK) fail(st, err);
+    });
+}
+
+int ire_debug_classifier_sums(ire_engine* e, int n, uint64_t* sums_out) {
+    return guarded([&] {
+        Engine& E = eng(e);
+        if (!sums_out) fail(IRE_ERR_INVALID_INPUT, "invalid output pointer");
+        std::lock_guard<std::mutex> lk(E.mutex());
+        E.debug_sums(n, sums_out);
+    });
+}
+
+int ire_debug_capture(ire_engine* e, int on) {
+    return guarded([&] {
+        Engine& E = eng(e);
+        std::lock_guard<std::mutex> lk(E.mutex());
+        E.debug_capture(on != 0);
+    });
+}
+
+int ire_debug_activation(ire_engine* e, const char* name, float* out, size_t* count) {
+    return guarded([&] {
+        Engine& E = eng(e);
+        if (!name) fail(IRE_ERR_INVALID_INPUT, "invalid activation name");
+        std::lock_guard<std::mutex> lk(E.mutex());
+        if (!E.debug_activation(name, out, count)) fail(IRE_ERR_INVALID_INPUT, std::string("invalid activation name: ") + name);
+    });
+}
+
+int ire_profile_enable(ire_engine* e, int on) {
+    return guarded([&] {
+        Engine& E = eng(e);
+        std::lock_guard<std::mutex> lk(E.mutex());
+        E.profile_enable(on != 0);
+    });
+}
+
+int ire_profile_query(ire_engine* e, const char* family, double* ms_out, int64_t* launches_out, double* flops_out,
+                      double* bytes_out) {
+    return guarded([&] {
+        Engine& E = eng(e);
+        const int fam = family_id(family);
+        std::lock_guard<std::mutex> lk(E.mutex());
+        E.profile_query(fam, ms_out, launches_out, flops_out, bytes_out);
+    });
+}
+
+int ire_profile_reset(ire_engine* e) {
+    return guarded([&] {
+        Engine& E = eng(e);
+        std::lock_guard<std::mutex> lk(E.mutex());
+        E.profile_reset();
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,39 @@
+// common.hpp -- shared host-side helpers for libire.so (error plumbing, HIP checks).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/ire.h"
+
+namespace ire {
+
+// Internal exception; converted to an ire_status + thread-local message at the C ABI.
+struct Error {
+    int code;
+    std::string msg;
+};
+
+void set_last_error(int code, const std::string& msg);
+
+[[noreturn]] inline void fail(int code, const std::string& msg) { throw Error{code, msg}; }
+
+inline void hip_check(hipError_t e, const char* what, const char* file, int line) {
+    if (e != hipSuccess) {
+        char buf[512];
+        std::snprintf(buf, sizeof(buf), "internal: %s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+        // a lost / absent device is reported as 503 so the worker's retry policy applies
+        int code = (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? IRE_ERR_UNAVAILABLE : IRE_ERR_INTERNAL;
+        if (code == IRE_ERR_UNAVAILABLE)
+            std::snprintf(buf, sizeof(buf), "service unavailable: %s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+        throw Error{code, buf};
+    }
+}
+#define IRE_HIP(expr) ::ire::hip_check((expr), #expr, __FILE__, __LINE__)
+
+template <typename T>
+inline T ceil_div(T a, T b) { return (a + b - 1) / b; }
+
+}  // namespace ire

@@ -1,0 +1,44 @@
+// conv_mfma.hpp -- launch interface of the MFMA convolution template (conv_mfma.hip).
+#pragma once
+#include "common.hpp"
+
+namespace ire {
+
+enum { PRO_NONE = 0, PRO_GN = 1, PRO_U8 = 2 };
+
+// The seven ways RestoreNet-v0 uses a convolution (DESIGN.md "RestoreNet-v0").
+enum ConvKind {
+    CONV_STEM,  // u8 RGB (padded to 8 ch) -> 32, 3x3, GroupNorm stats out
+    CONV_RB1,   // C->C 3x3, GN+FiLM+SiLU prologue, stats out
+    CONV_RB2,   // C->C 3x3, GN+FiLM+SiLU prologue, + residual, stats out
+    CONV_DOWN,  // C->2C 3x3 stride 2, stats out
+    CONV_UP,    // nearest x2 then 2C->C 3x3
+    CONV_FUSE,  // concat(up, skip) 2C->C 1x1, stats out
+    CONV_HEAD   // GN+SiLU prologue, 32->3 3x3, out = clamp(round(input + y)) u8
+};
+
+struct ConvArgs {
+    const void* in0;             // bf16 NHWC activations (CONV_STEM: u8 RGB)
+    const void* in1;             // second source of the concat (CONV_FUSE), else null
+    int cin0, cin1;              // channels per pixel of in0 / in1
+    int kc_split;                // number of 32-channel K-chunks read from in0 (rest from in1)
+    int nkc;                     // total K-chunks
+    const unsigned short* w;     // weights pre-arranged [nblock][kchunk][kk][NT][8] bf16
+    const float* bias;           // [cout]
+    const float2* ab;            // [nimg][cin0] GroupNorm+FiLM coefficients (PRO_GN)
+    const unsigned short* resid; // [nimg][Hout][Wout][cout] bf16 (CONV_RB2)
+    unsigned short* out;         // [nimg][Hout][Wout][cout] bf16
+    const unsigned char* u8_in;  // CONV_HEAD: original image
+    unsigned char* u8_out;       // CONV_HEAD: restored image
+    float* stats;                // [nimg][tiles][8][2] partial (sum, sumsq) per GroupNorm group
+    int Hin, Win, Hout, Wout, cout;
+    int tiles_x, tiles_y, nimg, nblocks;
+    int group_size;              // cout / 8
+};
+
+int conv_tile_h(ConvKind kind);       // output rows per workgroup tile (columns: 32)
+int conv_nt(ConvKind kind, int cout); // output channels per workgroup
+int conv_nsteps(ConvKind kind);       // MFMA k-steps per K-chunk (weight slab = nsteps*2*NT*16 B)
+void conv_launch(ConvKind kind, const ConvArgs& a, hipStream_t stream);
+
+}  // namespace ire

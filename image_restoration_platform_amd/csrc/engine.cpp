@@ -1,0 +1,604 @@
+// engine.cpp -- engine object: weights, workspaces, layer schedule, lanes, profiler.
+// See engine.hpp for the design; the layer schedule follows DESIGN.md "RestoreNet-v0"
+// (SURVEY.md Appendix C), which stands behind GeminiClient.restoreImage
+// (server-node/src/clients/geminiClient.js:32-97).
+#include "engine.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <fstream>
+
+#include "gn.hpp"
+#include "grey_tables.inc"
+
+namespace ire {
+
+namespace {
+
+const int kWidths[4] = {32, 64, 128, 256};
+const int kFilmOff[4] = {0, 64, 192, 448};
+const int kFilmDim = 960;
+
+inline unsigned short f32_to_bf16(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;  // weights are finite: no NaN handling needed
+    return (unsigned short)u;
+}
+
+}  // namespace
+
+void* Engine::dalloc(size_t bytes) {
+    void* p = nullptr;
+    IRE_HIP(hipMalloc(&p, bytes ? bytes : 16));
+    return p;
+}
+
+Engine::Engine(const ire_config& cfg) {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        fail(IRE_ERR_UNAVAILABLE, "service unavailable: no HIP device visible (the engine has no CPU fallback)");
+    device_ = cfg.device_index;
+    if (device_ < 0 || device_ >= ndev) fail(IRE_ERR_INVALID_INPUT, "invalid device_index");
+    IRE_HIP(hipSetDevice(device_));
+    hipDeviceProp_t prop;
+    IRE_HIP(hipGetDeviceProperties(&prop, device_));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        fail(IRE_ERR_UNAVAILABLE, std::string("service unavailable: device is ") + prop.gcnArchName +
+                                      ", this engine is built for gfx950 (MI355X) only");
+    if (cfg.precision != IRE_PRECISION_BF16) fail(IRE_ERR_INVALID_INPUT, "invalid precision: only bf16 is implemented");
+    max_batch_ = cfg.max_batch > 0 ? cfg.max_batch : 8;
+    if (max_batch_ > 64) fail(IRE_ERR_INVALID_INPUT, "invalid max_batch (1..64)");
+    num_lanes_ = cfg.num_streams > 0 ? cfg.num_streams : 1;
+    if (num_lanes_ > 16) num_lanes_ = 16;
+    flags_ = cfg.flags;
+
+    IRE_HIP(hipStreamCreateWithFlags(&main_stream_, hipStreamNonBlocking));
+    for (auto& ev : ev_) IRE_HIP(hipEventCreate(&ev));
+    IRE_HIP(hipEventCreateWithFlags(&fork_ev_, hipEventDisableTiming));
+    lanes_.resize(num_lanes_);
+    for (auto& L : lanes_) {
+        IRE_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        IRE_HIP(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+    }
+
+    // classifier tables
+    unsigned int* d_lin = (unsigned int*)dalloc(sizeof(kLin16));
+    unsigned int* d_thr = (unsigned int*)dalloc(sizeof(kGreyThr));
+    unsigned char* d_inv = (unsigned char*)dalloc(sizeof(kGreyInv));
+    table_allocs_ = {d_lin, d_thr, d_inv};
+    IRE_HIP(hipMemcpy(d_lin, kLin16, sizeof(kLin16), hipMemcpyHostToDevice));
+    IRE_HIP(hipMemcpy(d_thr, kGreyThr, sizeof(kGreyThr), hipMemcpyHostToDevice));
+    IRE_HIP(hipMemcpy(d_inv, kGreyInv, sizeof(kGreyInv), hipMemcpyHostToDevice));
+    tables_ = ClassifierTables{d_lin, d_thr, d_inv};
+
+    if (cfg.weights_path && cfg.weights_path[0]) load_weights_file(cfg.weights_path);
+}
+
+Engine::~Engine() {
+    (void)hipSetDevice(device_);
+    (void)hipDeviceSynchronize();
+    free_workspace();
+    for (void* p : net_.allocs) (void)hipFree(p);
+    for (void* p : table_allocs_) (void)hipFree(p);
+    for (void* p : {(void*)d_in_, (void*)d_out_, (void*)d_jpeg_, (void*)d_sums_, (void*)d_scores_, (void*)d_label_,
+                    (void*)d_cond_, (void*)d_film_})
+        if (p) (void)hipFree(p);
+    for (auto& L : lanes_) {
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+        if (L.done) (void)hipEventDestroy(L.done);
+    }
+    for (auto& ev : ev_) if (ev) (void)hipEventDestroy(ev);
+    if (fork_ev_) (void)hipEventDestroy(fork_ev_);
+    for (auto& r : prof_) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (auto ev : ev_pool_) (void)hipEventDestroy(ev);
+    if (main_stream_) (void)hipStreamDestroy(main_stream_);
+}
+
+// ------------------------------------------------------------------------------------------------
+// weights
+// ------------------------------------------------------------------------------------------------
+void Engine::load_weights_file(const char* path) {
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) fail(IRE_ERR_INVALID_INPUT, std::string("invalid weights_path: cannot open ") + path);
+    std::streamsize sz = f.tellg();
+    f.seekg(0);
+    std::vector<char> blob((size_t)sz);
+    if (!f.read(blob.data(), sz)) fail(IRE_ERR_INVALID_INPUT, std::string("invalid weights_path: short read ") + path);
+    load_weights(blob.data(), blob.size());
+}
+
+ConvW Engine::make_conv(ConvKind kind, const std::string& wname, const std::string& bname, int cin, int cout) {
+    auto wi = host_w_.find(wname), bi = host_w_.find(bname);
+    if (wi == host_w_.end() || bi == host_w_.end()) fail(IRE_ERR_INVALID_INPUT, "invalid weight file: missing " + wname);
+    const auto& dims = wi->second.first;
+    const int taps = (kind == CONV_FUSE) ? 1 : 9, ks = (kind == CONV_FUSE) ? 1 : 3;
+    if (dims.size() != 4 || dims[0] != cout || dims[1] != cin || dims[2] != ks || dims[3] != ks ||
+        (int)bi->second.second.size() != cout)
+        fail(IRE_ERR_INVALID_INPUT, "invalid weight file: shape of " + wname);
+    const float* W = wi->second.second.data();
+    ConvW c;
+    c.kind = kind; c.cin = cin; c.cout = cout;
+    const int kc8 = (kind == CONV_STEM) ? 1 : 4;
+    const int cin_pad = (kind == CONV_STEM) ? 8 : cin;
+    const int cout_pad = (kind == CONV_HEAD) ? 32 : cout;
+    c.nt = conv_nt(kind, cout_pad);
+    if (cin_pad % (kc8 * 8) || cout_pad % c.nt) fail(IRE_ERR_INTERNAL, "internal: conv channel counts");
+    c.nkc = cin_pad / (kc8 * 8);
+    c.nblocks = cout_pad / c.nt;
+    if (kind == CONV_FUSE) { c.cin0 = cin / 2; c.cin1 = cin / 2; c.kc_split = c.nkc / 2; }
+    else { c.cin0 = cin_pad; c.cin1 = 0; c.kc_split = c.nkc; }
+    const int nsteps = conv_nsteps(kind), nkk = nsteps * 2;
+    // slab layout [nblock][kchunk][kk = tap*kc8 + c8][n][e]; element = W[cout][cin = kc*kc8*8 + c8*8 + e][tap]
+    std::vector<unsigned short> arr((size_t)c.nblocks * c.nkc * nkk * c.nt * 8, 0);
+    for (int nb = 0; nb < c.nblocks; ++nb)
+        for (int kc = 0; kc < c.nkc; ++kc)
+            for (int kk = 0; kk < taps * kc8; ++kk) {
+                const int tap = kk / kc8, c8 = kk % kc8;
+                for (int n = 0; n < c.nt; ++n) {
+                    const int co = nb * c.nt + n;
+                    if (co >= cout) continue;
+                    for (int e = 0; e < 8; ++e) {
+                        const int ci = kc * kc8 * 8 + c8 * 8 + e;
+                        if (ci >= cin) continue;
+                        const float v = W[((size_t)co * cin + ci) * taps + tap];
+                        arr[((((size_t)nb * c.nkc + kc) * nkk + kk) * c.nt + n) * 8 + e] = f32_to_bf16(v);
+                    }
+                }
+            }
+    c.d_w = (unsigned short*)dalloc(arr.size() * 2);
+    net_.allocs.push_back(c.d_w);
+    IRE_HIP(hipMemcpy(c.d_w, arr.data(), arr.size() * 2, hipMemcpyHostToDevice));
+    std::vector<float> bias(cout_pad, 0.f);
+    std::memcpy(bias.data(), bi->second.second.data(), sizeof(float) * cout);
+    c.d_bias = (float*)dalloc(bias.size() * 4);
+    net_.allocs.push_back(c.d_bias);
+    IRE_HIP(hipMemcpy(c.d_bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+    return c;
+}
+
+GNW Engine::make_gn(const std::string& prefix, int C, int level) {
+    GNW g;
+    g.C = C; g.level = level;
+    for (int k = 0; k < 2; ++k) {
+        const std::string nm = prefix + (k == 0 ? ".g" : ".b");
+        auto it = host_w_.find(nm);
+        if (it == host_w_.end() || (int)it->second.second.size() != C)
+            fail(IRE_ERR_INVALID_INPUT, "invalid weight file: missing " + nm);
+        float* d = (float*)dalloc(sizeof(float) * C);
+        net_.allocs.push_back(d);
+        IRE_HIP(hipMemcpy(d, it->second.second.data(), sizeof(float) * C, hipMemcpyHostToDevice));
+        (k == 0 ? g.d_gamma : g.d_beta) = d;
+    }
+    return g;
+}
+
+RBW Engine::make_rb(const std::string& p, int C, int level) {
+    RBW r;
+    r.gn1 = make_gn(p + ".gn1", C, level);
+    r.conv1 = make_conv(CONV_RB1, p + ".conv1.w", p + ".conv1.b", C, C);
+    r.gn2 = make_gn(p + ".gn2", C, level);
+    r.conv2 = make_conv(CONV_RB2, p + ".conv2.w", p + ".conv2.b", C, C);
+    return r;
+}
+
+void Engine::load_weights(const void* blob, size_t bytes) {
+    const unsigned char* p = (const unsigned char*)blob;
+    auto need = [&](size_t off, size_t n) {
+        if (off + n > bytes) fail(IRE_ERR_INVALID_INPUT, "invalid weight file: truncated");
+    };
+    need(0, 12);
+    if (std::memcmp(p, "IREW", 4) != 0) fail(IRE_ERR_INVALID_INPUT, "invalid weight file: bad magic");
+    uint32_t ver, nt;
+    std::memcpy(&ver, p + 4, 4);
+    std::memcpy(&nt, p + 8, 4);
+    if (ver != 1 || nt > 4096) fail(IRE_ERR_INVALID_INPUT, "invalid weight file: version");
+    size_t off = 12;
+    host_w_.clear();
+    for (uint32_t i = 0; i < nt; ++i) {
+        uint32_t ln, nd;
+        need(off, 4); std::memcpy(&ln, p + off, 4); off += 4;
+        if (ln > 256) fail(IRE_ERR_INVALID_INPUT, "invalid weight file: name");
+        need(off, ln);
+        std::string name((const char*)p + off, ln); off += ln;
+        while (!name.empty() && name.back() == '\0') name.pop_back();
+        need(off, 4); std::memcpy(&nd, p + off, 4); off += 4;
+        if (nd > 4) fail(IRE_ERR_INVALID_INPUT, "invalid weight file: ndim");
+        std::vector<int> dims(nd);
+        size_t cnt = 1;
+        for (uint32_t d = 0; d < nd; ++d) {
+            uint32_t v; need(off, 4); std::memcpy(&v, p + off, 4); off += 4;
+            dims[d] = (int)v; cnt *= v;
+        }
+        need(off, cnt * 4);
+        std::vector<float> data(cnt);
+        std::memcpy(data.data(), p + off, cnt * 4); off += cnt * 4;
+        host_w_[name] = {dims, std::move(data)};
+    }
+    IRE_HIP(hipSetDevice(device_));
+    IRE_HIP(hipDeviceSynchronize());
+    for (void* q : net_.allocs) (void)hipFree(q);
+    net_ = Net{};
+    net_.stem = make_conv(CONV_STEM, "stem.w", "stem.b", 3, 32);
+    for (int l = 0; l < 4; ++l) {
+        for (int i = 0; i < 2; ++i)
+            net_.enc[l][i] = make_rb("enc" + std::to_string(l) + ".rb" + std::to_string(i), kWidths[l], l);
+        if (l < 3) net_.down[l] = make_conv(CONV_DOWN, "down" + std::to_string(l) + ".w", "down" + std::to_string(l) + ".b",
+                                           kWidths[l], kWidths[l + 1]);
+    }
+    for (int i = 0; i < 2; ++i) net_.mid[i] = make_rb("mid.rb" + std::to_string(i), 256, 3);
+    for (int l = 2; l >= 0; --l) {
+        const std::string s = std::to_string(l);
+        net_.up[l] = make_conv(CONV_UP, "up" + s + ".w", "up" + s + ".b", kWidths[l + 1], kWidths[l]);
+        net_.fuse[l] = make_conv(CONV_FUSE, "fuse" + s + ".w", "fuse" + s + ".b", 2 * kWidths[l], kWidths[l]);
+        for (int i = 0; i < 2; ++i) net_.dec[l][i] = make_rb("dec" + s + ".rb" + std::to_string(i), kWidths[l], l);
+    }
+    net_.head_gn = make_gn("head.gn", 32, 0);
+    net_.head = make_conv(CONV_HEAD, "head.w", "head.b", 32, 3);
+    {
+        auto fw = host_w_.find("film.w"), fb = host_w_.find("film.b");
+        if (fw == host_w_.end() || fb == host_w_.end() || (int)fw->second.second.size() != kFilmDim * 7 ||
+            (int)fb->second.second.size() != kFilmDim)
+            fail(IRE_ERR_INVALID_INPUT, "invalid weight file: film");
+        net_.d_film_w = (float*)dalloc(sizeof(float) * kFilmDim * 7);
+        net_.d_film_b = (float*)dalloc(sizeof(float) * kFilmDim);
+        net_.allocs.push_back(net_.d_film_w);
+        net_.allocs.push_back(net_.d_film_b);
+        IRE_HIP(hipMemcpy(net_.d_film_w, fw->second.second.data(), sizeof(float) * kFilmDim * 7, hipMemcpyHostToDevice));
+        IRE_HIP(hipMemcpy(net_.d_film_b, fb->second.second.data(), sizeof(float) * kFilmDim, hipMemcpyHostToDevice));
+    }
+    host_w_.clear();
+    net_.loaded = true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// buffers
+// ------------------------------------------------------------------------------------------------
+void Engine::check_shape(int n, int h, int w, bool for_restore) const {
+    if (n <= 0 || n > max_batch_) fail(IRE_ERR_INVALID_INPUT, "invalid batch size n (1..max_batch)");
+    if (h <= 0 || w <= 0 || h > 8192 || w > 8192) fail(IRE_ERR_INVALID_INPUT, "invalid image size");
+    if (for_restore && (h % 8 || w % 8 || h < 16 || w < 16))
+        fail(IRE_ERR_INVALID_INPUT, "invalid image size for restore: height and width must be multiples of 8, >= 16");
+}
+
+void Engine::ensure_io(int n, int h, int w) {
+    IRE_HIP(hipSetDevice(device_));
+    const size_t px = (size_t)h * w;
+    if ((size_t)n <= io_cap_imgs_ && px <= io_cap_px_) return;
+    IRE_HIP(hipDeviceSynchronize());
+    const size_t imgs = std::max<size_t>(io_cap_imgs_, (size_t)max_batch_);
+    const size_t cap_px = std::max(io_cap_px_, px);
+    for (void* p : {(void*)d_in_, (void*)d_out_, (void*)d_jpeg_, (void*)d_sums_, (void*)d_scores_, (void*)d_label_,
+                    (void*)d_cond_, (void*)d_film_})
+        if (p) (void)hipFree(p);
+    d_in_ = (uint8_t*)dalloc(imgs * cap_px * 3);
+    d_out_ = (uint8_t*)dalloc(imgs * cap_px * 3);
+    d_jpeg_ = (uint8_t*)dalloc(imgs);
+    d_sums_ = (unsigned long long*)dalloc(imgs * 14 * 8);
+    d_scores_ = (double*)dalloc(imgs * 7 * 8);
+    d_label_ = (int32_t*)dalloc(imgs * 4);
+    d_cond_ = (float*)dalloc(imgs * 8 * 4);
+    d_film_ = (float*)dalloc(imgs * kFilmDim * 4);
+    io_cap_imgs_ = imgs;
+    io_cap_px_ = cap_px;
+}
+
+void Engine::free_workspace() {
+    for (void* p : ws_allocs_) (void)hipFree(p);
+    ws_allocs_.clear();
+    for (auto& L : lanes_) {
+        std::memset(L.act, 0, sizeof(L.act));
+        std::memset(L.skip, 0, sizeof(L.skip));
+        L.stats = nullptr;
+        L.ab = nullptr;
+    }
+    ws_imgs_per_lane_ = ws_h_ = ws_w_ = 0;
+}
+
+void Engine::ensure_workspace(int n, int h, int w) {
+    (void)n;
+    const int per = ceil_div(max_batch_, num_lanes_);
+    if (per == ws_imgs_per_lane_ && h == ws_h_ && w == ws_w_) return;
+    IRE_HIP(hipDeviceSynchronize());
+    free_workspace();
+    for (auto& L : lanes_) {
+        for (int l = 0; l < 4; ++l) {
+            const size_t bytes = (size_t)per * (h >> l) * (w >> l) * kWidths[l] * 2;
+            for (int b = 0; b < 4; ++b) { L.act[l][b] = (unsigned short*)dalloc(bytes); ws_allocs_.push_back(L.act[l][b]); }
+            if (l < 3) { L.skip[l] = (unsigned short*)dalloc(bytes); ws_allocs_.push_back(L.skip[l]); }
+        }
+        const size_t tiles0 = (size_t)ceil_div(h, 4) * ceil_div(w, 32);
+        L.stats = (float*)dalloc((size_t)per * tiles0 * 16 * 4);
+        L.ab = (float2*)dalloc((size_t)per * 256 * sizeof(float2));
+        ws_allocs_.push_back(L.stats);
+        ws_allocs_.push_back(L.ab);
+    }
+    ws_imgs_per_lane_ = per; ws_h_ = h; ws_w_ = w;
+}
+
+// ------------------------------------------------------------------------------------------------
+// profiler (HIP events on the stream the kernel is launched on)
+// ------------------------------------------------------------------------------------------------
+void Engine::prof_begin(int fam, hipStream_t s, double flops, double bytes) {
+    if (!prof_on_) return;
+    ProfRec r;
+    r.fam = fam; r.flops = flops; r.bytes = bytes;
+    auto get = [&]() {
+        hipEvent_t ev;
+        if (!ev_pool_.empty()) { ev = ev_pool_.back(); ev_pool_.pop_back(); }
+        else IRE_HIP(hipEventCreate(&ev));
+        return ev;
+    };
+    r.e0 = get(); r.e1 = get();
+    IRE_HIP(hipEventRecord(r.e0, s));
+    prof_.push_back(r);
+}
+void Engine::prof_end(hipStream_t s) {
+    if (!prof_on_) return;
+    IRE_HIP(hipEventRecord(prof_.back().e1, s));
+}
+void Engine::prof_collect() {
+    if (prof_.empty()) return;
+    IRE_HIP(hipDeviceSynchronize());
+    for (auto& r : prof_) {
+        float ms = 0.f;
+        IRE_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+        prof_ms_[r.fam] += ms; prof_flops_[r.fam] += r.flops; prof_bytes_[r.fam] += r.bytes; prof_n_[r.fam] += 1;
+        ev_pool_.push_back(r.e0); ev_pool_.push_back(r.e1);
+    }
+    prof_.clear();
+}
+void Engine::profile_enable(bool on) { prof_collect(); prof_on_ = on; }
+void Engine::profile_reset() {
+    prof_collect();
+    for (int i = 0; i < FAM_COUNT; ++i) { prof_ms_[i] = prof_flops_[i] = prof_bytes_[i] = 0; prof_n_[i] = 0; }
+}
+void Engine::profile_query(int fam, double* ms, int64_t* launches, double* flops, double* bytes) {
+    prof_collect();
+    double m = 0, f = 0, b = 0; int64_t n = 0;
+    for (int i = 0; i < FAM_COUNT; ++i)
+        if (fam < 0 || fam == i) { m += prof_ms_[i]; f += prof_flops_[i]; b += prof_bytes_[i]; n += prof_n_[i]; }
+    if (ms) *ms = m;
+    if (launches) *launches = n;
+    if (flops) *flops = f;
+    if (bytes) *bytes = b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// debug capture
+// ------------------------------------------------------------------------------------------------
+void Engine::capture(const char* name, const unsigned short* d, size_t count, hipStream_t s) {
+    if (!capture_ || !name) return;
+    IRE_HIP(hipStreamSynchronize(s));
+    std::vector<unsigned short> hbuf(count);
+    IRE_HIP(hipMemcpy(hbuf.data(), d, count * 2, hipMemcpyDeviceToHost));
+    std::vector<float> f(count);
+    for (size_t i = 0; i < count; ++i) {
+        uint32_t u = (uint32_t)hbuf[i] << 16;
+        std::memcpy(&f[i], &u, 4);
+    }
+    captured_[name] = std::move(f);
+}
+bool Engine::debug_activation(const std::string& name, float* out, size_t* count) {
+    auto it = captured_.find(name);
+    if (it == captured_.end()) return false;
+    if (count) *count = it->second.size();
+    if (out) std::memcpy(out, it->second.data(), it->second.size() * sizeof(float));
+    return true;
+}
+void Engine::debug_sums(int n, uint64_t* out) {
+    if (n <= 0 || (size_t)n > io_cap_imgs_ || !d_sums_) fail(IRE_ERR_INVALID_INPUT, "invalid n for debug sums");
+    IRE_HIP(hipDeviceSynchronize());
+    IRE_HIP(hipMemcpy(out, d_sums_, sizeof(uint64_t) * 14 * n, hipMemcpyDeviceToHost));
+}
+
+// ------------------------------------------------------------------------------------------------
+// RestoreNet-v0 schedule
+// ------------------------------------------------------------------------------------------------
+void Engine::launch_conv(Lane& L, const ConvW& cw, const void* in0, const void* in1, const float2* ab,
+                         const unsigned short* resid, unsigned short* out, const uint8_t* u8_in, uint8_t* u8_out,
+                         int nimg, int Hin, int Win, int Hout, int Wout, const char* cap_name) {
+    ConvArgs a{};
+    a.in0 = in0; a.in1 = in1; a.cin0 = cw.cin0; a.cin1 = cw.cin1; a.kc_split = cw.kc_split; a.nkc = cw.nkc;
+    a.w = cw.d_w; a.bias = cw.d_bias; a.ab = ab; a.resid = resid; a.out = out; a.u8_in = u8_in; a.u8_out = u8_out;
+    a.stats = L.stats;
+    a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout;
+    a.cout = (cw.kind == CONV_HEAD) ? 32 : cw.cout;
+    a.tiles_x = ceil_div(Wout, 32);
+    a.tiles_y = ceil_div(Hout, conv_tile_h(cw.kind));
+    a.nimg = nimg; a.nblocks = cw.nblocks;
+    a.group_size = std::max(1, a.cout / 8);
+    const int taps = (cw.kind == CONV_FUSE) ? 1 : 9;
+    const double px = (double)nimg * Hout * Wout;
+    const double flops = 2.0 * taps * cw.cin * cw.cout * px;
+    const double in_px = (double)nimg * Hin * Win;
+    double bytes = in_px * cw.cin * (cw.kind == CONV_STEM ? 1 : 2) + px * cw.cout * (cw.kind == CONV_HEAD ? 1 : 2);
+    if (cw.kind == CONV_RB2) bytes += px * cw.cout * 2;
+    if (cw.kind == CONV_HEAD) bytes += px * 3;
+    int fam = FAM_CONV3;
+    if (cw.kind == CONV_FUSE) fam = FAM_CONV1;
+    else if (cw.kind == CONV_STEM) fam = FAM_STEM;
+    else if (cw.kind == CONV_HEAD) fam = FAM_HEAD;
+    prof_begin(fam, L.stream, flops, bytes);
+    conv_launch(cw.kind, a, L.stream);
+    prof_end(L.stream);
+    if (capture_ && cap_name && out) capture(cap_name, out, (size_t)nimg * Hout * Wout * cw.cout, L.stream);
+}
+
+void Engine::launch_gn(Lane& L, const GNW& g, int nimg, int Ht, int Wt, int ntiles, const float* d_film) {
+    prof_begin(FAM_GN, L.stream, 0, 0);
+    gn_finalize_launch(L.stats, nimg, ntiles, g.C, Ht * Wt, g.d_gamma, g.d_beta, d_film, kFilmDim, kFilmOff[g.level],
+                       L.ab, L.stream);
+    prof_end(L.stream);
+}
+
+void Engine::run_network(Lane& L, int nimg, int h, int w, const uint8_t* d_in, uint8_t* d_out, const float* d_film) {
+    auto tiles = [&](int Ht, int Wt, int th) { return ceil_div(Wt, 32) * ceil_div(Ht, th); };
+    // ResBlock: out = x + conv2(silu(gn2(conv1(silu(gn1(x)))))); stats of x are in L.stats on entry,
+    // stats of out are in L.stats on exit.
+    auto resblock = [&](const RBW& rb, const unsigned short* x, unsigned short* tmp, unsigned short* out, int l,
+                        int x_tiles, const std::string& name) {
+        const int Ht = h >> l, Wt = w >> l;
+        launch_gn(L, rb.gn1, nimg, Ht, Wt, x_tiles, d_film);
+        launch_conv(L, rb.conv1, x, nullptr, L.ab, nullptr, tmp, nullptr, nullptr, nimg, Ht, Wt, Ht, Wt,
+                    capture_ ? (name + ".h").c_str() : nullptr);
+        launch_gn(L, rb.gn2, nimg, Ht, Wt, tiles(Ht, Wt, 8), d_film);
+        launch_conv(L, rb.conv2, tmp, nullptr, L.ab, x, out, nullptr, nullptr, nimg, Ht, Wt, Ht, Wt,
+                    capture_ ? name.c_str() : nullptr);
+    };
+
+    // stem
+    launch_conv(L, net_.stem, d_in, nullptr, nullptr, nullptr, L.act[0][0], nullptr, nullptr, nimg, h, w, h, w, "stem");
+    int cur_tiles = tiles(h, w, 8);
+    const unsigned short* x = L.act[0][0];
+    // encoder
+    for (int l = 0; l < 4; ++l) {
+        const int Ht = h >> l, Wt = w >> l;
+        unsigned short* rb1_out = (l < 3) ? L.skip[l] : L.act[l][3];
+        resblock(net_.enc[l][0], x, L.act[l][1], L.act[l][2], l, cur_tiles, "enc" + std::to_string(l) + ".rb0");
+        resblock(net_.enc[l][1], L.act[l][2], L.act[l][1], rb1_out, l, tiles(Ht, Wt, 8), "enc" + std::to_string(l) + ".rb1");
+        if (l < 3) {
+            launch_conv(L, net_.down[l], rb1_out, nullptr, nullptr, nullptr, L.act[l + 1][0], nullptr, nullptr, nimg, Ht,
+                        Wt, Ht / 2, Wt / 2, capture_ ? ("down" + std::to_string(l)).c_str() : nullptr);
+            x = L.act[l + 1][0];
+            cur_tiles = tiles(Ht / 2, Wt / 2, 4);
+        }
+    }
+    // bottleneck at level 3
+    {
+        const int Ht = h >> 3, Wt = w >> 3;
+        resblock(net_.mid[0], L.act[3][3], L.act[3][1], L.act[3][0], 3, tiles(Ht, Wt, 8), "mid.rb0");
+        resblock(net_.mid[1], L.act[3][0], L.act[3][1], L.act[3][2], 3, tiles(Ht, Wt, 8), "mid.rb1");
+    }
+    const unsigned short* deep = L.act[3][2];
+    // decoder
+    for (int l = 2; l >= 0; --l) {
+        const int Ht = h >> l, Wt = w >> l;
+        const std::string s = std::to_string(l);
+        launch_conv(L, net_.up[l], deep, nullptr, nullptr, nullptr, L.act[l][0], nullptr, nullptr, nimg, Ht / 2, Wt / 2, Ht,
+                    Wt, capture_ ? ("up" + s).c_str() : nullptr);
+        launch_conv(L, net_.fuse[l], L.act[l][0], L.skip[l], nullptr, nullptr, L.act[l][2], nullptr, nullptr, nimg, Ht, Wt,
+                    Ht, Wt, capture_ ? ("fuse" + s).c_str() : nullptr);
+        resblock(net_.dec[l][0], L.act[l][2], L.act[l][1], L.act[l][3], l, tiles(Ht, Wt, 8), "dec" + s + ".rb0");
+        resblock(net_.dec[l][1], L.act[l][3], L.act[l][1], L.act[l][0], l, tiles(Ht, Wt, 8), "dec" + s + ".rb1");
+        deep = L.act[l][0];
+    }
+    // head
+    launch_gn(L, net_.head_gn, nimg, h, w, tiles(h, w, 8), d_film);
+    launch_conv(L, net_.head, deep, nullptr, L.ab, nullptr, nullptr, d_in, d_out, nimg, h, w, h, w, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// entry points
+// ------------------------------------------------------------------------------------------------
+void Engine::classify_device(const uint8_t* d_rgb, int n, int h, int w, const uint8_t* d_is_jpeg, double* d_scores,
+                             int32_t* d_label, hipStream_t stream) {
+    check_shape(n, h, w, false);
+    if (!d_rgb) fail(IRE_ERR_INVALID_INPUT, "invalid input: null image pointer");
+    ensure_io(n, 1, 1);
+    Lane tmp; tmp.stream = stream;
+    prof_begin(FAM_CLASSIFIER, stream, 0, (double)n * h * w * 3);
+    classifier_launch(tables_, d_rgb, n, h, w, d_is_jpeg, d_sums_, d_scores ? d_scores : d_scores_, d_label ? d_label : d_label_,
+                      d_cond_, stream);
+    prof_end(stream);
+    last_n_ = n;
+}
+
+void Engine::restore_device(const uint8_t* d_rgb, int n, int h, int w, const double* d_scores, const uint8_t* d_is_jpeg,
+                            uint8_t* d_out, hipStream_t stream) {
+    check_shape(n, h, w, true);
+    if (!net_.loaded) fail(IRE_ERR_UNAVAILABLE, "service unavailable: RestoreNet weights are not loaded");
+    if (!d_rgb || !d_out) fail(IRE_ERR_INVALID_INPUT, "invalid input: null image pointer");
+    ensure_io(n, 1, 1);
+    ensure_workspace(n, h, w);
+    if (d_scores) {
+        scores_to_cond_launch(d_scores, n, d_cond_, stream);
+    } else {
+        prof_begin(FAM_CLASSIFIER, stream, 0, (double)n * h * w * 3);
+        classifier_launch(tables_, d_rgb, n, h, w, d_is_jpeg, d_sums_, d_scores_, d_label_, d_cond_, stream);
+        prof_end(stream);
+    }
+    prof_begin(FAM_GN, stream, 0, 0);
+    film_launch(d_cond_, n, net_.d_film_w, net_.d_film_b, kFilmDim, d_film_, stream);
+    prof_end(stream);
+    last_n_ = n;
+
+    const int lanes_used = std::min(num_lanes_, n);
+    const size_t img_bytes = (size_t)h * w * 3;
+    if (lanes_used == 1) {
+        Lane L = lanes_[0];
+        L.stream = stream;  // run inline on the caller's stream
+        run_network(L, n, h, w, d_rgb, d_out, d_film_);
+        return;
+    }
+    const int per = ceil_div(n, lanes_used);
+    IRE_HIP(hipEventRecord(fork_ev_, stream));
+    for (int i = 0; i < lanes_used; ++i) {
+        const int i0 = i * per, cnt = std::min(per, n - i0);
+        if (cnt <= 0) break;
+        Lane& L = lanes_[i];
+        IRE_HIP(hipStreamWaitEvent(L.stream, fork_ev_, 0));
+        run_network(L, cnt, h, w, d_rgb + (size_t)i0 * img_bytes, d_out + (size_t)i0 * img_bytes,
+                    d_film_ + (size_t)i0 * kFilmDim);
+        IRE_HIP(hipEventRecord(L.done, L.stream));
+        IRE_HIP(hipStreamWaitEvent(stream, L.done, 0));
+    }
+}
+
+void Engine::classify_host(const uint8_t* rgb, int n, int h, int w, int row_stride, const uint8_t* is_jpeg, double* scores,
+                           int32_t* label) {
+    check_shape(n, h, w, false);
+    if (!rgb || !scores) fail(IRE_ERR_INVALID_INPUT, "invalid input: null pointer");
+    if (row_stride < 3 * w) fail(IRE_ERR_INVALID_INPUT, "invalid row_stride (< 3*w)");
+    ensure_io(n, h, w);
+    hipStream_t s = main_stream_;
+    IRE_HIP(hipMemcpy2DAsync(d_in_, (size_t)3 * w, rgb, (size_t)row_stride, (size_t)3 * w, (size_t)n * h, hipMemcpyHostToDevice, s));
+    std::vector<uint8_t> jp(n, 1);
+    if (is_jpeg) std::memcpy(jp.data(), is_jpeg, n);
+    IRE_HIP(hipMemcpyAsync(d_jpeg_, jp.data(), n, hipMemcpyHostToDevice, s));
+    classify_device(d_in_, n, h, w, d_jpeg_, d_scores_, d_label_, s);
+    IRE_HIP(hipMemcpyAsync(scores, d_scores_, sizeof(double) * 7 * n, hipMemcpyDeviceToHost, s));
+    if (label) IRE_HIP(hipMemcpyAsync(label, d_label_, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+    IRE_HIP(hipStreamSynchronize(s));
+}
+
+void Engine::restore_host(const uint8_t* rgb, int n, int h, int w, const double* scores, const uint8_t* is_jpeg,
+                          uint8_t* out, ire_timings* t) {
+    check_shape(n, h, w, true);
+    if (!rgb || !out) fail(IRE_ERR_INVALID_INPUT, "invalid input: null pointer");
+    ensure_io(n, h, w);
+    hipStream_t s = main_stream_;
+    const size_t bytes = (size_t)n * h * w * 3;
+    IRE_HIP(hipEventRecord(ev_[0], s));
+    IRE_HIP(hipMemcpyAsync(d_in_, rgb, bytes, hipMemcpyHostToDevice, s));
+    std::vector<uint8_t> jp(n, 1);
+    if (is_jpeg) std::memcpy(jp.data(), is_jpeg, n);
+    IRE_HIP(hipMemcpyAsync(d_jpeg_, jp.data(), n, hipMemcpyHostToDevice, s));
+    const double* d_sc = nullptr;
+    IRE_HIP(hipEventRecord(ev_[1], s));
+    if (scores) {
+        IRE_HIP(hipMemcpyAsync(d_scores_, scores, sizeof(double) * 7 * n, hipMemcpyHostToDevice, s));
+        d_sc = d_scores_;
+    } else {
+        // classify as its own step so classify_ms / restore_ms mirror restorator.js:59-95
+        prof_begin(FAM_CLASSIFIER, s, 0, (double)n * h * w * 3);
+        classifier_launch(tables_, d_in_, n, h, w, d_jpeg_, d_sums_, d_scores_, d_label_, d_cond_, s);
+        prof_end(s);
+        d_sc = d_scores_;
+    }
+    IRE_HIP(hipEventRecord(ev_[2], s));
+    restore_device(d_in_, n, h, w, d_sc, d_jpeg_, d_out_, s);
+    IRE_HIP(hipEventRecord(ev_[3], s));
+    IRE_HIP(hipMemcpyAsync(out, d_out_, bytes, hipMemcpyDeviceToHost, s));
+    IRE_HIP(hipStreamSynchronize(s));
+    if (t) {
+        float a = 0, b = 0, c = 0;
+        IRE_HIP(hipEventElapsedTime(&a, ev_[1], ev_[2]));
+        IRE_HIP(hipEventElapsedTime(&b, ev_[2], ev_[3]));
+        IRE_HIP(hipEventElapsedTime(&c, ev_[0], ev_[3]));
+        t->classify_ms = a; t->restore_ms = b; t->total_ms = c;
+    }
+}
+
+}  // namespace ire

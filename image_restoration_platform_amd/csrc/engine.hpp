@@ -1,0 +1,157 @@
+// engine.hpp -- the per-GPU engine object behind the C ABI (include/ire.h).
+//
+// One engine = one process = one MI355X.  It owns: the classifier tables, the RestoreNet-v0
+// weights re-laid-out for conv_mfma.hip, per-"lane" activation workspaces (a lane = one HIP
+// stream restoring a contiguous slice of the batch, so several images are in flight and the
+// per-image working set of the full-resolution levels stays inside the 256 MiB Infinity Cache),
+// staging buffers for the host-pointer entry points, and an event-based per-kernel profiler.
+#pragma once
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "classifier.hpp"
+#include "common.hpp"
+#include "conv_mfma.hpp"
+
+namespace ire {
+
+enum Family { FAM_CLASSIFIER = 0, FAM_CONV3 = 1, FAM_CONV1 = 2, FAM_STEM = 3, FAM_HEAD = 4, FAM_GN = 5,
+              FAM_FUSION = 6, FAM_COUNT = 7 };
+
+struct ConvW {
+    ConvKind kind = CONV_RB1;
+    int cin = 0, cout = 0;       // logical channel counts (FLOP accounting)
+    int cin0 = 0, cin1 = 0;      // channels per pixel of the two sources
+    int nt = 0, nblocks = 0, nkc = 0, kc_split = 0;
+    unsigned short* d_w = nullptr;
+    float* d_bias = nullptr;
+};
+struct GNW {
+    int C = 0, level = 0;
+    float* d_gamma = nullptr;
+    float* d_beta = nullptr;
+};
+struct RBW {
+    GNW gn1, gn2;
+    ConvW conv1, conv2;
+};
+struct Net {
+    bool loaded = false;
+    ConvW stem, head;
+    GNW head_gn;
+    RBW enc[4][2], mid[2], dec[3][2];
+    ConvW down[3], up[3], fuse[3];
+    float* d_film_w = nullptr;
+    float* d_film_b = nullptr;
+    std::vector<void*> allocs;
+};
+
+struct Lane {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    unsigned short* act[4][4] = {};
+    unsigned short* skip[3] = {};
+    float* stats = nullptr;
+    float2* ab = nullptr;
+};
+
+struct ProfRec {
+    int fam;
+    hipEvent_t e0, e1;
+    double flops, bytes;
+};
+
+class Engine {
+public:
+    explicit Engine(const ire_config& cfg);
+    ~Engine();
+
+    void load_weights(const void* blob, size_t bytes);
+    void load_weights_file(const char* path);
+
+    // host-pointer paths (synchronous)
+    void classify_host(const uint8_t* rgb, int n, int h, int w, int row_stride, const uint8_t* is_jpeg,
+                       double* scores, int32_t* label);
+    void restore_host(const uint8_t* rgb, int n, int h, int w, const double* scores, const uint8_t* is_jpeg,
+                      uint8_t* out, ire_timings* t);
+    // device-pointer paths (asynchronous on stream)
+    void classify_device(const uint8_t* d_rgb, int n, int h, int w, const uint8_t* d_is_jpeg, double* d_scores,
+                         int32_t* d_label, hipStream_t stream);
+    void restore_device(const uint8_t* d_rgb, int n, int h, int w, const double* d_scores,
+                        const uint8_t* d_is_jpeg, uint8_t* d_out, hipStream_t stream);
+
+    void debug_sums(int n, uint64_t* out);
+    void debug_capture(bool on) { capture_ = on; captured_.clear(); }
+    bool debug_activation(const std::string& name, float* out, size_t* count);
+
+    void profile_enable(bool on);
+    void profile_reset();
+    void profile_query(int fam, double* ms, int64_t* launches, double* flops, double* bytes);
+
+    int max_batch() const { return max_batch_; }
+    std::mutex& mutex() { return mu_; }
+
+private:
+    void check_shape(int n, int h, int w, bool for_restore) const;
+    void ensure_io(int n, int h, int w);
+    void ensure_workspace(int n, int h, int w);
+    void free_workspace();
+    void run_network(Lane& L, int nimg, int h, int w, const uint8_t* d_in, uint8_t* d_out, const float* d_film);
+    void launch_conv(Lane& L, const ConvW& cw, const void* in0, const void* in1, const float2* ab,
+                     const unsigned short* resid, unsigned short* out, const uint8_t* u8_in, uint8_t* u8_out,
+                     int nimg, int Hin, int Win, int Hout, int Wout, const char* cap_name);
+    void launch_gn(Lane& L, const GNW& g, int nimg, int Ht, int Wt, int ntiles, const float* d_film);
+    void prof_begin(int fam, hipStream_t s, double flops, double bytes);
+    void prof_end(hipStream_t s);
+    void capture(const char* name, const unsigned short* d, size_t count, hipStream_t s);
+    ConvW make_conv(ConvKind kind, const std::string& wname, const std::string& bname, int cin, int cout);
+    GNW make_gn(const std::string& prefix, int C, int level);
+    RBW make_rb(const std::string& prefix, int C, int level);
+    void* dalloc(size_t bytes);
+
+    int device_ = 0;
+    int max_batch_ = 8;
+    int num_lanes_ = 1;
+    uint32_t flags_ = 0;
+    std::mutex mu_;
+    hipStream_t main_stream_ = nullptr;
+    hipEvent_t ev_[4] = {};
+    hipEvent_t fork_ev_ = nullptr;
+
+    // classifier
+    ClassifierTables tables_{};
+    std::vector<void*> table_allocs_;
+
+    // io / classifier buffers (sized by ensure_io)
+    size_t io_cap_imgs_ = 0, io_cap_px_ = 0;
+    uint8_t* d_in_ = nullptr;
+    uint8_t* d_out_ = nullptr;
+    uint8_t* d_jpeg_ = nullptr;
+    unsigned long long* d_sums_ = nullptr;
+    double* d_scores_ = nullptr;
+    int32_t* d_label_ = nullptr;
+    float* d_cond_ = nullptr;
+    float* d_film_ = nullptr;
+    int last_n_ = 0;
+
+    // network
+    Net net_;
+    std::map<std::string, std::pair<std::vector<int>, std::vector<float>>> host_w_;
+    std::vector<Lane> lanes_;
+    int ws_imgs_per_lane_ = 0, ws_h_ = 0, ws_w_ = 0;
+    std::vector<void*> ws_allocs_;
+
+    // debug / profile
+    bool capture_ = false;
+    std::map<std::string, std::vector<float>> captured_;
+    bool prof_on_ = false;
+    std::vector<ProfRec> prof_;
+    std::vector<hipEvent_t> ev_pool_;
+    double prof_ms_[FAM_COUNT] = {}, prof_flops_[FAM_COUNT] = {}, prof_bytes_[FAM_COUNT] = {};
+    int64_t prof_n_[FAM_COUNT] = {};
+    void prof_collect();
+};
+
+}  // namespace ire

@@ -1,0 +1,200 @@
+"""Python host binding of the engine's C ABI (include/ire.h) -- numpy and torch-tensor front ends.
+
+This is the "PyTorch-ROCm extension" side of BASELINE.json's north_star: torch supplies device
+memory and streams (tensor.data_ptr(), torch.cuda.current_stream()), the engine does the work.
+Nothing here computes pixels on the CPU; if libire.so or the GPU is missing every call raises.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib, weights as _weights
+
+KEYS = ["blur", "noise", "lowLight", "compression", "scratch", "fade", "colorShift"]  # classifier.js:62-70
+FAMILIES = ["classifier", "conv3x3", "conv1x1", "stem", "head", "gn_finalize", "fusion", "all"]
+
+
+class EngineError(RuntimeError):
+    """Raised for a non-zero ire_status; .message feeds RestoratorService._classifyError
+    (restorator.js:241-265): it contains 'invalid' / 'timeout' / 'service unavailable'."""
+
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+        self.message = message
+        self.code = {1: "ENGINE_INVALID_INPUT", 2: "ENGINE_TIMEOUT", 3: "ENGINE_UNAVAILABLE"}.get(status, "ENGINE_INTERNAL")
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None else None
+
+
+class Engine:
+    def __init__(self, device_index=0, max_batch=8, num_streams=0, weights_path="default", seed=0, flags=0):
+        self._lib = _lib.load()
+        if weights_path == "default":
+            weights_path = _weights.ensure_default(seed)
+        cfg = _lib.IreConfig()
+        cfg.struct_size = ctypes.sizeof(_lib.IreConfig)
+        cfg.device_index = device_index
+        cfg.precision = 0
+        cfg.max_batch = max_batch
+        cfg.num_streams = num_streams
+        cfg.weights_path = weights_path.encode() if weights_path else None
+        cfg.flags = flags
+        h = ctypes.c_void_p()
+        self._h = None
+        self._check(self._lib.ire_init(ctypes.byref(cfg), ctypes.byref(h)))
+        self._h = h
+        self.max_batch = max_batch
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._lib.ire_last_error()
+            raise EngineError(rc, msg.decode() if msg else f"engine error {rc}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ire_shutdown(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host (numpy) -------------------------------------------------------------------------
+    @staticmethod
+    def _as_batch(rgb):
+        rgb = np.asarray(rgb)
+        if rgb.dtype != np.uint8:
+            raise EngineError(1, "invalid input: image dtype must be uint8")
+        if rgb.ndim == 3:
+            rgb = rgb[None]
+        if rgb.ndim != 4 or rgb.shape[3] != 3:
+            raise EngineError(1, "invalid input: expected [N,H,W,3] uint8")
+        return np.ascontiguousarray(rgb)
+
+    def classify(self, rgb, is_jpeg=True):
+        """-> (scores [N,7] float64, labels [N] int32).  ClassifierService.analyze (classifier.js:40)."""
+        rgb = self._as_batch(rgb)
+        n, h, w, _ = rgb.shape
+        jp = np.ascontiguousarray(np.broadcast_to(np.asarray(is_jpeg, dtype=np.uint8), (n,)))
+        scores = np.zeros((n, 7), np.float64)
+        labels = np.zeros(n, np.int32)
+        self._check(self._lib.ire_classify(self._h, _ptr(rgb), n, h, w, 3 * w, _ptr(jp), _ptr(scores), _ptr(labels)))
+        return scores, labels
+
+    def restore(self, rgb, scores=None, is_jpeg=True, return_timings=False):
+        """-> restored [N,H,W,3] uint8.  The step behind GeminiClient.restoreImage (geminiClient.js:32)."""
+        rgb = self._as_batch(rgb)
+        n, h, w, _ = rgb.shape
+        jp = np.ascontiguousarray(np.broadcast_to(np.asarray(is_jpeg, dtype=np.uint8), (n,)))
+        sc = None
+        if scores is not None:
+            sc = np.ascontiguousarray(np.asarray(scores, dtype=np.float64).reshape(n, 7))
+        out = np.empty_like(rgb)
+        t = _lib.IreTimings()
+        self._check(self._lib.ire_restore(self._h, _ptr(rgb), n, h, w, _ptr(sc), _ptr(jp), _ptr(out), ctypes.byref(t)))
+        if return_timings:
+            return out, {"classify_ms": t.classify_ms, "restore_ms": t.restore_ms, "total_ms": t.total_ms}
+        return out
+
+    def fuse(self, views, noise_score=-1.0):
+        """views [k,H,W,3] uint8, k in 2..3 -> (fused [H,W,3], shifts [k,2] (dy,dx))."""
+        views = self._as_batch(views)
+        k, h, w, _ = views.shape
+        out = np.empty((h, w, 3), np.uint8)
+        shifts = np.zeros((k, 2), np.int32)
+        t = _lib.IreTimings()
+        self._check(self._lib.ire_fuse(self._h, _ptr(views), k, h, w, float(noise_score), _ptr(out), _ptr(shifts),
+                                       ctypes.byref(t)))
+        return out, shifts
+
+    def submit(self, rgb, is_jpeg=True):
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        h, w, _ = rgb.shape
+        job = ctypes.c_void_p()
+        self._check(self._lib.ire_submit(self._h, _ptr(rgb), h, w, int(bool(is_jpeg)), ctypes.byref(job)))
+        return (job, h, w)
+
+    def poll(self, job, timeout_ms=-1):
+        handle, h, w = job
+        out = np.empty((h, w, 3), np.uint8)
+        scores = np.zeros(7, np.float64)
+        t = _lib.IreTimings()
+        self._check(self._lib.ire_poll(self._h, handle, timeout_ms, _ptr(out), _ptr(scores), ctypes.byref(t)))
+        return out, scores, {"classify_ms": t.classify_ms, "restore_ms": t.restore_ms, "total_ms": t.total_ms}
+
+    # ---- device (torch tensors) ---------------------------------------------------------------
+    @staticmethod
+    def _stream_ptr(stream):
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream()
+        return ctypes.c_void_p(s.cuda_stream)
+
+    def classify_tensor(self, rgb_u8, is_jpeg_u8=None, stream=None):
+        """rgb_u8: cuda uint8 [N,H,W,3] contiguous -> (scores cuda float64 [N,7], labels cuda int32 [N])."""
+        import torch
+        assert rgb_u8.is_cuda and rgb_u8.dtype == torch.uint8 and rgb_u8.is_contiguous() and rgb_u8.dim() == 4
+        n, h, w, _ = rgb_u8.shape
+        scores = torch.empty((n, 7), dtype=torch.float64, device=rgb_u8.device)
+        labels = torch.empty((n,), dtype=torch.int32, device=rgb_u8.device)
+        jp = ctypes.c_void_p(is_jpeg_u8.data_ptr()) if is_jpeg_u8 is not None else None
+        self._check(self._lib.ire_classify_device(self._h, ctypes.c_void_p(rgb_u8.data_ptr()), n, h, w, jp,
+                                                  ctypes.c_void_p(scores.data_ptr()), ctypes.c_void_p(labels.data_ptr()),
+                                                  self._stream_ptr(stream)))
+        return scores, labels
+
+    def restore_tensor(self, rgb_u8, out_u8=None, scores=None, is_jpeg_u8=None, stream=None):
+        """Asynchronous on the torch stream: classify (unless scores given) + RestoreNet-v0."""
+        import torch
+        assert rgb_u8.is_cuda and rgb_u8.dtype == torch.uint8 and rgb_u8.is_contiguous() and rgb_u8.dim() == 4
+        n, h, w, _ = rgb_u8.shape
+        if out_u8 is None:
+            out_u8 = torch.empty_like(rgb_u8)
+        sc = ctypes.c_void_p(scores.data_ptr()) if scores is not None else None
+        jp = ctypes.c_void_p(is_jpeg_u8.data_ptr()) if is_jpeg_u8 is not None else None
+        self._check(self._lib.ire_restore_device(self._h, ctypes.c_void_p(rgb_u8.data_ptr()), n, h, w, sc, jp,
+                                                 ctypes.c_void_p(out_u8.data_ptr()), self._stream_ptr(stream)))
+        return out_u8
+
+    def fuse_tensor(self, views_u8, noise_score=-1.0, stream=None):
+        import torch
+        assert views_u8.is_cuda and views_u8.dtype == torch.uint8 and views_u8.is_contiguous() and views_u8.dim() == 4
+        k, h, w, _ = views_u8.shape
+        out = torch.empty((h, w, 3), dtype=torch.uint8, device=views_u8.device)
+        shifts = torch.zeros((k, 2), dtype=torch.int32, device=views_u8.device)
+        self._check(self._lib.ire_fuse_device(self._h, ctypes.c_void_p(views_u8.data_ptr()), k, h, w, float(noise_score),
+                                              ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(shifts.data_ptr()),
+                                              self._stream_ptr(stream)))
+        return out, shifts
+
+    # ---- diagnostics --------------------------------------------------------------------------
+    def classifier_sums(self, n):
+        sums = np.zeros((n, 14), np.uint64)
+        self._check(self._lib.ire_debug_classifier_sums(self._h, n, _ptr(sums)))
+        return sums
+
+    def debug_capture(self, on=True):
+        self._check(self._lib.ire_debug_capture(self._h, int(on)))
+
+    def activation(self, name):
+        cnt = ctypes.c_size_t(0)
+        self._check(self._lib.ire_debug_activation(self._h, name.encode(), None, ctypes.byref(cnt)))
+        out = np.zeros(cnt.value, np.float32)
+        self._check(self._lib.ire_debug_activation(self._h, name.encode(), _ptr(out), ctypes.byref(cnt)))
+        return out
+
+    def profile_enable(self, on=True):
+        self._check(self._lib.ire_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        self._check(self._lib.ire_profile_reset(self._h))
+
+    def profile_query(self, family="all"):
+        ms, n, fl, by = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+        self._check(self._lib.ire_profile_query(self._h, family.encode(), ctypes.byref(ms), ctypes.byref(n),
+                                                ctypes.byref(fl), ctypes.byref(by)))
+        return {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}

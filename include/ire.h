@@ -1,0 +1,150 @@
+/*
+ * ire.h -- C ABI of libire.so, the MI355X-native image-restoration engine.
+ *
+ * This is the drop-in boundary for the reference's queue-worker hot path
+ * (degradation classification -> restoration -> optional <=3-image fusion).
+ * The reference has no FFI of its own; its seams are two
+ * duck-typed JS objects, and every entry point below names the reference
+ * interface it stands behind:
+ *
+ *   ire_classify*  <- ClassifierService.analyze(Buffer) -> {7 scores}
+ *                     server-node/src/services/classifier.js:40-99
+ *                     (+ the ranking derived in promptEnhancer.js:121-136)
+ *   ire_restore*   <- GeminiClient.restoreImage({prompt, images:[buf], userContext})
+ *                     server-node/src/clients/geminiClient.js:32-97, called from
+ *                     server-node/src/services/restorator.js:88-94
+ *   ire_fuse*      <- the same restoreImage seam with images.length in 2..3
+ *                     (geminiClient.js:32,49; docs only: image-restoration-platform.md:787-857)
+ *   ire_submit/ire_poll <- restoreBatch's in-flight promises
+ *                     server-node/src/services/restorator.js:181-236 (p-limit 3)
+ *
+ * Conventions: plain pointers and sizes only; the caller owns every buffer; the
+ * engine never keeps an input pointer past return (past ire_poll completion for
+ * ire_submit); one engine may be used from several threads; no exceptions cross
+ * the ABI.  Every call returns an ire_status; ire_last_error() gives the
+ * thread-local message, which always contains one of the substrings
+ * "invalid", "timeout", "service unavailable" so that the reference's
+ * RestoratorService._classifyError (restorator.js:241-265) maps it the way it
+ * maps provider errors.  Images are decoded 8-bit sRGB, NHWC interleaved RGB
+ * (what sharp(buf).raw() yields: SURVEY.md Appendix A.1); decode/encode lives
+ * in the host adapters.  There is NO CPU fallback: without a gfx950 device
+ * ire_init fails with IRE_ERR_UNAVAILABLE.
+ */
+#ifndef IRE_H
+#define IRE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IRE_ABI_VERSION 1
+
+typedef enum ire_status {
+    IRE_OK = 0,
+    IRE_ERR_INVALID_INPUT = 1, /* message contains "invalid"             -> INVALID_INPUT       */
+    IRE_ERR_TIMEOUT = 2,       /* message contains "timeout"             -> TIMEOUT             */
+    IRE_ERR_UNAVAILABLE = 3,   /* message contains "service unavailable" -> SERVICE_UNAVAILABLE */
+    IRE_ERR_INTERNAL = 4
+} ire_status;
+
+enum { IRE_PRECISION_BF16 = 0, IRE_PRECISION_FP8 = 1 /* reserved: rejected in this ABI version */ };
+
+/* Score order = the object-literal order of classifier.js:62-70. */
+enum { IRE_SCORE_BLUR = 0, IRE_SCORE_NOISE, IRE_SCORE_LOWLIGHT, IRE_SCORE_COMPRESSION,
+       IRE_SCORE_SCRATCH, IRE_SCORE_FADE, IRE_SCORE_COLORSHIFT, IRE_NUM_SCORES };
+
+typedef struct ire_engine ire_engine;
+
+typedef struct ire_config {
+    uint32_t struct_size;     /* = sizeof(ire_config); lets the struct grow              */
+    int32_t device_index;     /* HIP device ordinal (one engine = one GPU = one process) */
+    int32_t precision;        /* IRE_PRECISION_BF16                                      */
+    int32_t max_batch;        /* images per call, 1..64 (default 8 when 0)               */
+    int32_t num_streams;      /* images restored concurrently on separate HIP streams
+                                 (default 0 = engine's choice)                           */
+    const char* weights_path; /* RestoreNet-v0 weight file (DESIGN.md "weight file");
+                                 NULL: classify/fuse only until ire_load_weights         */
+    uint32_t flags;           /* IRE_FLAG_*                                              */
+} ire_config;
+
+#define IRE_FLAG_NO_GRAPH 1u /* launch kernels eagerly instead of replaying hipGraphs */
+
+typedef struct ire_timings { /* GPU time measured with HIP events on the engine's stream; mirrors
+                                timings.classify_ms / restore_ms of restorator.js:48-98         */
+    double classify_ms;
+    double restore_ms;
+    double total_ms;
+} ire_timings;
+
+/* ---- lifecycle ------------------------------------------------------------------------ */
+int ire_abi_version(void);
+int ire_init(const ire_config* cfg, ire_engine** out);
+void ire_shutdown(ire_engine* e);
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* ire_last_error(void);
+/* Load RestoreNet-v0 weights from memory (same bytes as the weight file). */
+int ire_load_weights(ire_engine* e, const void* blob, size_t bytes);
+/* Images (N*H*W*3 u8 + activations) the engine can hold for this shape; 0 if unsupported. */
+int ire_max_batch_for(ire_engine* e, int h, int w);
+
+/* ---- host-buffer entry points (synchronous; copy in, run, copy out) -------------------- */
+/* analyze(): n images of h x w, rows row_stride bytes apart (>= 3*w), images n apart by
+ * h*row_stride.  is_jpeg[i] != 0 <=> metadata.format === 'jpeg' (classifier.js:180).
+ * scores_out: n*7 doubles; label_out: n int32 = first-max argmax in key order (may be NULL). */
+int ire_classify(ire_engine* e, const uint8_t* rgb, int n, int h, int w, int row_stride,
+                 const uint8_t* is_jpeg, double* scores_out, int32_t* label_out);
+/* restoreImage() with one image per job: out_rgb is n*h*w*3 (tightly packed).  scores==NULL
+ * => classify inside (is_jpeg then required); else n*7 doubles used as conditioning.
+ * h and w must be multiples of 8 (three stride-2 levels), >= 16. */
+int ire_restore(ire_engine* e, const uint8_t* rgb, int n, int h, int w, const double* scores,
+                const uint8_t* is_jpeg, uint8_t* out_rgb, ire_timings* t);
+/* restoreImage() with k = 2..3 views of one scene: align to view 0 and blend.  out: h*w*3.
+ * noise_score: the classifier's noise score of view 0 (sets the blend sigma); <0 => classify inside. */
+int ire_fuse(ire_engine* e, const uint8_t* rgb_views, int k, int h, int w, double noise_score,
+             uint8_t* out_rgb, int32_t* shifts_out /* k*2 (dy,dx), may be NULL */, ire_timings* t);
+
+/* ---- device-buffer entry points (asynchronous on `stream`, a hipStream_t or NULL) ------ */
+/* Same semantics; every pointer is device memory of e's GPU, tightly packed. The FastAPI /
+ * PyTorch-ROCm host and bench.py use these with tensor.data_ptr() and the torch stream. */
+int ire_classify_device(ire_engine* e, const uint8_t* d_rgb, int n, int h, int w,
+                        const uint8_t* d_is_jpeg, double* d_scores, int32_t* d_label, void* stream);
+int ire_restore_device(ire_engine* e, const uint8_t* d_rgb, int n, int h, int w,
+                       const double* d_scores /* NULL => classify inside */, const uint8_t* d_is_jpeg,
+                       uint8_t* d_out_rgb, void* stream);
+int ire_fuse_device(ire_engine* e, const uint8_t* d_rgb_views, int k, int h, int w, double noise_score,
+                    uint8_t* d_out_rgb, int32_t* d_shifts, void* stream);
+
+/* ---- async batcher (restoreBatch's in-flight promises) ---------------------------------- */
+typedef struct ire_job ire_job;
+/* Queue one h x w image for restoration; jobs of equal shape are coalesced into batches of up
+ * to max_batch.  The input is copied before return. */
+int ire_submit(ire_engine* e, const uint8_t* rgb, int h, int w, int is_jpeg, ire_job** job_out);
+/* Wait up to timeout_ms (<0: forever) for the job; on IRE_OK out_rgb (h*w*3), scores_out (7, may
+ * be NULL) and t (may be NULL) are filled and the job is released.  IRE_ERR_TIMEOUT leaves the
+ * job pending. */
+int ire_poll(ire_engine* e, ire_job* job, int timeout_ms, uint8_t* out_rgb, double* scores_out,
+             ire_timings* t);
+
+/* ---- measurement / diagnostics (used by bench.py and tests; not part of the job path) --- */
+/* Raw integer accumulators of the classifier scan for n images (14 u64 each, order documented in
+ * csrc/classifier_finalize.hpp) of the last classify / restore call, copied to host. */
+int ire_debug_classifier_sums(ire_engine* e, int n, uint64_t* sums_out);
+/* Turn per-layer capture on/off (slow: synchronises after every layer; tests only). */
+int ire_debug_capture(ire_engine* e, int on);
+/* Copy one named intermediate activation of the last ire_restore* call to host as float32 NHWC.
+ * Returns the element count through *count (call with out==NULL to query). */
+int ire_debug_activation(ire_engine* e, const char* name, float* out, size_t* count);
+/* Accumulated HIP-event time (ms) and launch count per kernel family since the last reset:
+ * family in {"classifier","conv3x3","conv1x1","stem","head","gn_finalize","fusion","all"}. */
+int ire_profile_enable(ire_engine* e, int on);
+int ire_profile_query(ire_engine* e, const char* family, double* ms_out, int64_t* launches_out,
+                      double* flops_out, double* bytes_out);
+int ire_profile_reset(ire_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IRE_H */
