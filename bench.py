@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""bench.py -- restored images/sec for the queue-worker hot path (classify + RestoreNet-v0).
+
+Workload (BASELINE.json metric): 1024x1024 RGB, batch 8 per GPU, synthetic,
+inputs resident in HBM when the timed region starts; a "step" = one batch through
+ire_restore_device (fused classifier scan + 43-conv U-Net + u8 store).  N > 1: one process per
+GPU, images sharded per rank with NO data-path collective (jobs are independent:
+restorator.js:198-211); only the timing barrier / max uses torch.distributed (RCCL).
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (the 3x3 conv family,
+HIP-event timed inside the engine on the launching stream) and `cpu_baseline` (the CPU oracle --
+test infrastructure -- timed on this box's host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md chip table
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(size, budget_s=25.0):
+    """Oracle (CPU restatement, kind='port') on a bounded sample: one size x size image."""
+    import numpy as np
+    import torch
+    from image_restoration_platform_amd import synth, weights
+    from oracle import classifier as oc
+    from oracle import restorenet as onet
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    img = synth.batch(1, size, size)
+    w = weights.generate(0)
+    t0 = time.perf_counter()
+    s, _ = oc.classify(img[0], True)
+    t1 = time.perf_counter()
+    onet.restore(img, s[None], w)
+    t2 = time.perf_counter()
+    return {"value": 1.0 / (t2 - t0), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"1 image {size}x{size}: C classifier oracle (1 thread) {1e3 * (t1 - t0):.0f} ms + "
+                      f"PyTorch-CPU fp32 RestoreNet oracle ({cores} threads) {t2 - t1:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("IRE_STREAMS", "0")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the in-engine HIP-event kernel timing")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from image_restoration_platform_amd import synth, weights
+    from image_restoration_platform_amd.engine import Engine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    B, S = args.batch, args.size
+    eng = Engine(device_index=local_rank, max_batch=B, num_streams=args.streams)
+    # per-rank shard of the job stream: rank r restores images r*B .. r*B+B-1
+    x = torch.from_numpy(synth.batch(B, S, S, start=rank * B)).to(dev)
+    jpeg = torch.ones(B, dtype=torch.uint8, device=dev)
+    out = torch.empty_like(x)
+
+    def step():
+        eng.restore_tensor(x, out, scores=None, is_jpeg_u8=jpeg)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    if not args.no_profile:
+        eng.profile_reset()
+        eng.profile_enable(True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = None
+    if not args.no_profile:
+        eng.profile_enable(False)
+        prof = {f: eng.profile_query(f) for f in ("conv3x3", "conv1x1", "stem", "head", "classifier", "gn_finalize", "all")}
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        f3, f1 = weights.conv_flops(S, S)
+        res = {
+            "metric": "restored images/sec @%dx%d bs=%d" % (S, S, B),
+            "value": world * args.steps * B / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "%dx%d RGB u8, batch %d per GPU: fused classifier scan + RestoreNet-v0 (43 convs, "
+                                   "%.1f GFLOP/image), seeded random-init weights" % (S, S, B, (f3 + f1) / 1e9),
+                       "global_batch": B * world, "parallelism": "per-image data parallel x%d, no collective" % world,
+                       "streams": args.streams},
+        }
+        if prof is not None:
+            c3 = prof["conv3x3"]
+            ach = c3["flops"] / (c3["ms"] * 1e-3) / 1e12 if c3["ms"] > 0 else 0.0
+            res["roofline"] = {
+                "kernel": "conv_mfma_kernel (all 3x3 C->C / down / up instantiations)", "bound": "mfma",
+                "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+                "traffic": None, "launches": c3["launches"], "avg_launch_us": 1e3 * c3["ms"] / max(1, c3["launches"]),
+                "algorithmic_gflop_per_launch": c3["flops"] / max(1, c3["launches"]) / 1e9,
+                "hbm_algorithmic_GBs": c3["bytes"] / (c3["ms"] * 1e-3) / 1e9 if c3["ms"] > 0 else 0.0,
+                "family_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
+            }
+            res["whole_net_mfma_frac"] = (f3 + f1) * B * args.steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(S)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
