@@ -1,0 +1,244 @@
+"""Host-side mirror of the reference's service layer for the hot path, wired to the engine.
+
+  RestoratorService        <- server-node/src/services/restorator.js:16-319
+  EngineClassifier         -> the duck-typed `classifier` seam  {analyze(buffer) -> {7 scores}}
+                              (restorator.js:24, classifier.js:40-99)
+  EngineRestorer           -> the duck-typed `geminiClient` seam {restore_image(prompt, images,
+                              user_context) -> {base64Image, metadata}} (geminiClient.js:32-97)
+
+Same names, argument meaning and error behaviour as the reference (snake_case methods, the
+result dict keeps the reference's camelCase keys because it is the wire envelope):
+restore() never raises, the error envelope defaults code 'RESTORATION_FAILED', _classify_error
+matches substrings, _determine_failure_stage tests the *truthiness* of integer-ms timings
+(Appendix B quirk pinned by tests/restoratorService.test.js:77).
+The adapters decode/encode on the host (PIL) and hand decoded RGB to the engine; there is no CPU
+pixel path: if the engine is unavailable they raise and restore() returns the error envelope.
+"""
+import base64
+import concurrent.futures
+import io
+import os
+import time
+import uuid
+from datetime import datetime, timezone
+
+import numpy as np
+
+from .prompt_enhancer import KEYS, PromptEnhancerService
+
+BATCH_REQUEST_DELAY_MS = float(os.environ.get("RESTORATION_BATCH_DELAY_MS", "0") or 0)  # restorator.js:13
+BATCH_CONCURRENCY = max(1, int(float(os.environ.get("RESTORATION_BATCH_CONCURRENCY", "3") or 3)))  # :14
+
+
+def _now_ms():
+    return int(time.time() * 1000)  # Date.now()
+
+
+def decode_image(buffer):
+    """encoded bytes -> (rgb uint8 [H,W,3], format str).  sharp(buf) decodes to 8-bit sRGB
+    (Appendix A.1); no EXIF rotation inside the classifier (A.2)."""
+    from PIL import Image
+    try:
+        im = Image.open(io.BytesIO(bytes(buffer)))
+        fmt = (im.format or "").lower()
+        im = im.convert("RGB")
+    except Exception as e:  # noqa: BLE001
+        raise ValueError(f"invalid image buffer: {e}") from e
+    return np.ascontiguousarray(np.asarray(im, dtype=np.uint8)), fmt
+
+
+def encode_png_base64(rgb):
+    from PIL import Image
+    bio = io.BytesIO()
+    Image.fromarray(rgb, "RGB").save(bio, format="PNG")
+    return base64.b64encode(bio.getvalue()).decode("ascii")
+
+
+def pad_to_multiple(rgb, m=8, min_size=16):
+    """edge-replicate pad so H, W are multiples of m (RestoreNet has three stride-2 levels)."""
+    h, w, _ = rgb.shape
+    H = max(min_size, (h + m - 1) // m * m)
+    W = max(min_size, (w + m - 1) // m * m)
+    if (H, W) == (h, w):
+        return rgb, (h, w)
+    return np.ascontiguousarray(np.pad(rgb, ((0, H - h), (0, W - w), (0, 0)), mode="edge")), (h, w)
+
+
+class EngineClassifier:
+    """classifier seam: analyze(imageBuffer) -> {blur, noise, lowLight, compression, scratch, fade, colorShift}."""
+
+    def __init__(self, engine, logger=None):
+        self.engine = engine
+        self.logger = logger
+
+    def analyze(self, image_buffer):
+        rgb, fmt = decode_image(image_buffer)
+        scores, _ = self.engine.classify(rgb, is_jpeg=(fmt == "jpeg"))
+        return {k: float(scores[0, i]) for i, k in enumerate(KEYS)}
+
+
+class EngineRestorer:
+    """geminiClient seam: restore_image(prompt, images, user_context) -> {base64Image, metadata}."""
+
+    def __init__(self, engine, logger=None):
+        self.engine = engine
+        self.logger = logger
+
+    def restore_image(self, prompt, images, user_context=None):
+        if not images or len(images) > 3:
+            raise ValueError("invalid images: expected 1..3 encoded images")  # provider limit: report.md:28
+        decoded = [decode_image(b) for b in images]
+        shapes = {d[0].shape for d in decoded}
+        if len(shapes) != 1:
+            raise ValueError("invalid images: fusion views must have identical dimensions")
+        restored = []
+        for rgb, fmt in decoded:
+            padded, (h, w) = pad_to_multiple(rgb)
+            out = self.engine.restore(padded, scores=None, is_jpeg=(fmt == "jpeg"))[0]
+            restored.append(np.ascontiguousarray(out[:h, :w]))
+        if len(restored) == 1:
+            result = restored[0]
+        else:
+            views = np.stack(restored, axis=0)
+            padded = np.stack([pad_to_multiple(v)[0] for v in views], axis=0)
+            fused, _ = self.engine.fuse(padded, noise_score=-1.0)
+            result = np.ascontiguousarray(fused[:views.shape[1], :views.shape[2]])
+        return {
+            "base64Image": encode_png_base64(result),
+            "metadata": {"providerRequestId": f"ire-{uuid.uuid4()}", "billedTokens": None, "estimatedCostUsd": 0},
+        }
+
+
+class RestoratorService:
+    """restorator.js:16-319."""
+
+    def __init__(self, gemini_client=None, logger=None, engine=None):
+        if gemini_client is None and engine is not None:
+            gemini_client = EngineRestorer(engine, logger)
+        if not gemini_client:
+            raise ValueError("RestoratorService requires a geminiClient")  # restorator.js:18-20
+        self.gemini_client = gemini_client
+        self.logger = logger
+        # public, replaceable by assignment like the reference's (restorator.js:24-25)
+        self.classifier = EngineClassifier(engine, logger) if engine is not None else None
+        self.prompt_enhancer = PromptEnhancerService(logger)
+
+    # -- restorator.js:37-172 -----------------------------------------------------------------
+    def restore(self, image_buffer, user_prompt=None, user_context=None, options=None):
+        options = {} if options is None else options
+        start = _now_ms()
+        timings = {}
+        try:
+            t0 = _now_ms()
+            if self.classifier is None:
+                raise RuntimeError("service unavailable: no classifier configured")
+            degradation = self.classifier.analyze(image_buffer)
+            timings["classify_ms"] = _now_ms() - t0
+
+            t0 = _now_ms()
+            enhanced_prompt = self.prompt_enhancer.enhance(degradation=degradation, user_prompt=user_prompt,
+                                                           options=options)
+            timings["prompt_ms"] = _now_ms() - t0
+
+            t0 = _now_ms()
+            result = self.gemini_client.restore_image(prompt=enhanced_prompt, images=[image_buffer],
+                                                      user_context=user_context)
+            timings["restore_ms"] = _now_ms() - t0
+            timings["total_ms"] = _now_ms() - start
+            md = result["metadata"]
+            return {
+                "success": True,
+                "restoredImage": result["base64Image"],
+                "degradationAnalysis": degradation,
+                "enhancedPrompt": enhanced_prompt,
+                "timings": timings,
+                "metadata": {
+                    "providerRequestId": md.get("providerRequestId"),
+                    "estimatedCostUsd": md.get("estimatedCostUsd"),
+                    "billedTokens": md.get("billedTokens"),
+                    "processingTime": timings["total_ms"],
+                    "classificationIssues": [{"type": k, "confidence": v} for k, v in degradation.items() if v > 0.3],
+                },
+            }
+        except Exception as error:  # noqa: BLE001 -- restore never raises (restorator.js:141-167)
+            timings["total_ms"] = _now_ms() - start
+            if self.logger is not None:
+                self.logger.error("[restorator] Restoration failed: %s", error)
+            return {
+                "success": False,
+                "error": {"message": str(error), "code": getattr(error, "code", None) or "RESTORATION_FAILED",
+                          "type": self._classify_error(error)},
+                "timings": timings,
+                "metadata": {"processingTime": timings["total_ms"],
+                             "failureStage": self._determine_failure_stage(timings)},
+            }
+
+    # -- restorator.js:181-236 ----------------------------------------------------------------
+    def restore_batch(self, images, user_prompt=None, user_context=None, options=None):
+        options = {} if options is None else options
+
+        def task(index, buf):
+            if BATCH_REQUEST_DELAY_MS > 0 and index > 0:
+                time.sleep(BATCH_REQUEST_DELAY_MS / 1000.0)
+            return self.restore(buf, user_prompt, user_context,
+                                {**options, "batchIndex": index, "batchSize": len(images)})
+
+        with concurrent.futures.ThreadPoolExecutor(max_workers=BATCH_CONCURRENCY) as ex:
+            futs = [ex.submit(task, i, b) for i, b in enumerate(images)]
+            return [f.result() for f in futs]  # same order as the input
+
+    # -- restorator.js:241-265 ----------------------------------------------------------------
+    @staticmethod
+    def _classify_error(error):
+        message = str(error).lower()
+        if "rate limit" in message or "429" in message:
+            return "RATE_LIMIT_EXCEEDED"
+        if "timeout" in message or "etimedout" in message:
+            return "TIMEOUT"
+        if "invalid" in message or "400" in message:
+            return "INVALID_INPUT"
+        if "unauthorized" in message or "401" in message:
+            return "AUTHENTICATION_FAILED"
+        if "service unavailable" in message or "503" in message:
+            return "SERVICE_UNAVAILABLE"
+        return "UNKNOWN_ERROR"
+
+    # -- restorator.js:270-284 (truthiness of ms values, 0 ms counts as "not run") ---------------
+    @staticmethod
+    def _determine_failure_stage(timings):
+        if timings.get("classify_ms") and not timings.get("prompt_ms"):
+            return "PROMPT_ENHANCEMENT"
+        if timings.get("prompt_ms") and not timings.get("restore_ms"):
+            return "AI_RESTORATION"
+        if not timings.get("classify_ms"):
+            return "CLASSIFICATION"
+        return "UNKNOWN"
+
+    # -- restorator.js:289-314 ----------------------------------------------------------------
+    def get_health_status(self):
+        """The reference probes the classifier with a 100-byte zero buffer, which sharp cannot
+        decode, so it reports classifier=False there; kept, plus an explicit
+        engine entry so /health/ready can tell "bad probe" from "no GPU"."""
+        try:
+            try:
+                self.classifier.analyze(bytes(100))
+                ok = True
+            except Exception:  # noqa: BLE001
+                ok = False
+            engine_ok = False
+            try:
+                eng = getattr(self.classifier, "engine", None)
+                if eng is not None:
+                    eng.classify(np.zeros((16, 16, 3), np.uint8))
+                    engine_ok = True
+            except Exception:  # noqa: BLE001
+                engine_ok = False
+            return {"healthy": ok, "services": {"classifier": ok, "promptEnhancer": True, "geminiClient": True,
+                                                "engine": engine_ok},
+                    "timestamp": datetime.now(timezone.utc).isoformat()}
+        except Exception as e:  # noqa: BLE001
+            return {"healthy": False, "error": str(e), "timestamp": datetime.now(timezone.utc).isoformat()}
+
+
+def create_restorator_service(gemini_client=None, logger=None, engine=None):
+    return RestoratorService(gemini_client=gemini_client, logger=logger, engine=engine)

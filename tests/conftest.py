@@ -1,0 +1,45 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_available():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def engine():
+    """One engine per test session, through the C ABI.  GPU tests must never pass on a fallback:
+    if the library or the device is missing this raises (it does not skip)."""
+    from image_restoration_platform_amd.engine import Engine
+    eng = Engine(device_index=0, max_batch=8, num_streams=1)
+    yield eng
+    eng.close()
+
+
+@pytest.fixture(scope="session")
+def weights0():
+    from image_restoration_platform_amd import weights
+    return weights.generate(0)
+
+
+def pytest_collection_modifyitems(config, items):
+    if _gpu_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
