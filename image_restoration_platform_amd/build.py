@@ -17,6 +17,7 @@ LIB = os.path.join(HERE, "lib", "libire.so")
 SOURCES = [
     ("classifier.hip", ["-ffp-contract=off"]),
     ("conv_mfma.hip", []),
+    ("conv_rb.hip", []),
     ("gn.hip", []),
     ("fusion.hip", []),
     ("engine.cpp", []),

@@ -41,4 +41,9 @@ int conv_nt(ConvKind kind, int cout); // output channels per workgroup
 int conv_nsteps(ConvKind kind);       // MFMA k-steps per K-chunk (weight slab = nsteps*2*NT*16 B)
 void conv_launch(ConvKind kind, const ConvArgs& a, hipStream_t stream);
 
+// Persistent software-pipelined variant for CONV_RB1 / CONV_RB2 (conv_rb.hip): 16x32 tiles
+// (a.tiles_y must be ceil(Hout/16)), same weight slab layout, same ConvArgs.
+constexpr int kRbTileH = 16;
+void conv_rb_launch(bool resid, const ConvArgs& a, hipStream_t stream);
+
 }  // namespace ire

@@ -5,6 +5,7 @@
 #include "engine.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 
@@ -53,6 +54,7 @@ Engine::Engine(const ire_config& cfg) {
     num_lanes_ = cfg.num_streams > 0 ? cfg.num_streams : 1;
     if (num_lanes_ > 16) num_lanes_ = 16;
     flags_ = cfg.flags;
+    if (const char* v = std::getenv("IRE_CONV_V1")) rb_tile_h_ = (v[0] == '1') ? 8 : kRbTileH;
 
     IRE_HIP(hipStreamCreateWithFlags(&main_stream_, hipStreamNonBlocking));
     for (auto& ev : ev_) IRE_HIP(hipEventCreate(&ev));
@@ -406,7 +408,8 @@ void Engine::launch_conv(Lane& L, const ConvW& cw, const void* in0, const void* 
     a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout;
     a.cout = (cw.kind == CONV_HEAD) ? 32 : cw.cout;
     a.tiles_x = ceil_div(Wout, 32);
-    a.tiles_y = ceil_div(Hout, conv_tile_h(cw.kind));
+    const bool rb = (cw.kind == CONV_RB1 || cw.kind == CONV_RB2);
+    a.tiles_y = ceil_div(Hout, rb ? rb_tile_h_ : conv_tile_h(cw.kind));
     a.nimg = nimg; a.nblocks = cw.nblocks;
     a.group_size = std::max(1, a.cout / 8);
     const int taps = (cw.kind == CONV_FUSE) ? 1 : 9;
@@ -421,7 +424,8 @@ void Engine::launch_conv(Lane& L, const ConvW& cw, const void* in0, const void* 
     else if (cw.kind == CONV_STEM) fam = FAM_STEM;
     else if (cw.kind == CONV_HEAD) fam = FAM_HEAD;
     prof_begin(fam, L.stream, flops, bytes);
-    conv_launch(cw.kind, a, L.stream);
+    if (rb && rb_tile_h_ == kRbTileH) conv_rb_launch(cw.kind == CONV_RB2, a, L.stream);
+    else conv_launch(cw.kind, a, L.stream);
     prof_end(L.stream);
     if (capture_ && cap_name && out) capture(cap_name, out, (size_t)nimg * Hout * Wout * cw.cout, L.stream);
 }
@@ -443,7 +447,7 @@ void Engine::run_network(Lane& L, int nimg, int h, int w, const uint8_t* d_in, u
         launch_gn(L, rb.gn1, nimg, Ht, Wt, x_tiles, d_film);
         launch_conv(L, rb.conv1, x, nullptr, L.ab, nullptr, tmp, nullptr, nullptr, nimg, Ht, Wt, Ht, Wt,
                     capture_ ? (name + ".h").c_str() : nullptr);
-        launch_gn(L, rb.gn2, nimg, Ht, Wt, tiles(Ht, Wt, 8), d_film);
+        launch_gn(L, rb.gn2, nimg, Ht, Wt, tiles(Ht, Wt, rb_tile_h_), d_film);
         launch_conv(L, rb.conv2, tmp, nullptr, L.ab, x, out, nullptr, nullptr, nimg, Ht, Wt, Ht, Wt,
                     capture_ ? name.c_str() : nullptr);
     };
@@ -457,7 +461,7 @@ void Engine::run_network(Lane& L, int nimg, int h, int w, const uint8_t* d_in, u
         const int Ht = h >> l, Wt = w >> l;
         unsigned short* rb1_out = (l < 3) ? L.skip[l] : L.act[l][3];
         resblock(net_.enc[l][0], x, L.act[l][1], L.act[l][2], l, cur_tiles, "enc" + std::to_string(l) + ".rb0");
-        resblock(net_.enc[l][1], L.act[l][2], L.act[l][1], rb1_out, l, tiles(Ht, Wt, 8), "enc" + std::to_string(l) + ".rb1");
+        resblock(net_.enc[l][1], L.act[l][2], L.act[l][1], rb1_out, l, tiles(Ht, Wt, rb_tile_h_), "enc" + std::to_string(l) + ".rb1");
         if (l < 3) {
             launch_conv(L, net_.down[l], rb1_out, nullptr, nullptr, nullptr, L.act[l + 1][0], nullptr, nullptr, nimg, Ht,
                         Wt, Ht / 2, Wt / 2, capture_ ? ("down" + std::to_string(l)).c_str() : nullptr);
@@ -468,8 +472,8 @@ void Engine::run_network(Lane& L, int nimg, int h, int w, const uint8_t* d_in, u
     // bottleneck at level 3
     {
         const int Ht = h >> 3, Wt = w >> 3;
-        resblock(net_.mid[0], L.act[3][3], L.act[3][1], L.act[3][0], 3, tiles(Ht, Wt, 8), "mid.rb0");
-        resblock(net_.mid[1], L.act[3][0], L.act[3][1], L.act[3][2], 3, tiles(Ht, Wt, 8), "mid.rb1");
+        resblock(net_.mid[0], L.act[3][3], L.act[3][1], L.act[3][0], 3, tiles(Ht, Wt, rb_tile_h_), "mid.rb0");
+        resblock(net_.mid[1], L.act[3][0], L.act[3][1], L.act[3][2], 3, tiles(Ht, Wt, rb_tile_h_), "mid.rb1");
     }
     const unsigned short* deep = L.act[3][2];
     // decoder
@@ -481,11 +485,11 @@ void Engine::run_network(Lane& L, int nimg, int h, int w, const uint8_t* d_in, u
         launch_conv(L, net_.fuse[l], L.act[l][0], L.skip[l], nullptr, nullptr, L.act[l][2], nullptr, nullptr, nimg, Ht, Wt,
                     Ht, Wt, capture_ ? ("fuse" + s).c_str() : nullptr);
         resblock(net_.dec[l][0], L.act[l][2], L.act[l][1], L.act[l][3], l, tiles(Ht, Wt, 8), "dec" + s + ".rb0");
-        resblock(net_.dec[l][1], L.act[l][3], L.act[l][1], L.act[l][0], l, tiles(Ht, Wt, 8), "dec" + s + ".rb1");
+        resblock(net_.dec[l][1], L.act[l][3], L.act[l][1], L.act[l][0], l, tiles(Ht, Wt, rb_tile_h_), "dec" + s + ".rb1");
         deep = L.act[l][0];
     }
     // head
-    launch_gn(L, net_.head_gn, nimg, h, w, tiles(h, w, 8), d_film);
+    launch_gn(L, net_.head_gn, nimg, h, w, tiles(h, w, rb_tile_h_), d_film);
     launch_conv(L, net_.head, deep, nullptr, L.ab, nullptr, nullptr, d_in, d_out, nimg, h, w, h, w, nullptr);
 }
 

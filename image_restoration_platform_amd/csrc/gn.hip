@@ -21,34 +21,37 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
                                                           const float* __restrict__ beta,
                                                           const float* __restrict__ film, int film_stride,
                                                           int film_off, float2* __restrict__ ab) {
-    __shared__ double red[32][8][2];
-    __shared__ float s_mean[8], s_rstd[8];
-    const int img = blockIdx.x, tid = threadIdx.x;
-    const int g = tid & 7, part = tid >> 3;  // 32 parts x 8 groups
+    // one workgroup per (image, group): fixed-order tree reduction of the tile partials in double
+    __shared__ double red[256][2];
+    __shared__ float s_mean, s_rstd;
+    const int img = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
     double s = 0.0, q = 0.0;
-    const float* st = stats + (size_t)img * ntiles * 16;
-    for (int t = part; t < ntiles; t += 32) {
-        s += (double)st[(size_t)t * 16 + g * 2];
-        q += (double)st[(size_t)t * 16 + g * 2 + 1];
+    const float2* st = reinterpret_cast<const float2*>(stats) + (size_t)img * ntiles * 8 + g;
+    for (int t = tid; t < ntiles; t += 256) {
+        const float2 v = st[(size_t)t * 8];
+        s += (double)v.x;
+        q += (double)v.y;
     }
-    red[part][g][0] = s;
-    red[part][g][1] = q;
+    red[tid][0] = s;
+    red[tid][1] = q;
     __syncthreads();
-    if (tid < 8) {
-        double ss = 0.0, qq = 0.0;
-        for (int p = 0; p < 32; ++p) { ss += red[p][tid][0]; qq += red[p][tid][1]; }
-        const double cnt = (double)hw * (double)(C / 8);
-        const double mean = ss / cnt;
-        double var = qq / cnt - mean * mean;
-        if (var < 0.0) var = 0.0;
-        s_mean[tid] = (float)mean;
-        s_rstd[tid] = (float)(1.0 / sqrt(var + 1e-5));
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (tid < off) { red[tid][0] += red[tid + off][0]; red[tid][1] += red[tid + off][1]; }
+        __syncthreads();
     }
-    __syncthreads();
     const int G = C / 8;
-    for (int c = tid; c < C; c += 256) {
-        const int gi = c / G;
-        const float rg = s_rstd[gi] * gamma[c];
+    if (tid == 0) {
+        const double cnt = (double)hw * (double)G;
+        const double mean = red[0][0] / cnt;
+        double var = red[0][1] / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mean = (float)mean;
+        s_rstd = (float)(1.0 / sqrt(var + 1e-5));
+    }
+    __syncthreads();
+    for (int k = tid; k < G; k += 256) {
+        const int c = g * G + k;
+        const float rg = s_rstd * gamma[c];
         float sc = 0.f, sh = 0.f;
         if (film) {
             sc = film[(size_t)img * film_stride + film_off + c];
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
         }
         float2 o;
         o.x = rg * (1.f + sc);
-        o.y = (beta[c] - s_mean[gi] * rg) * (1.f + sc) + sh;
+        o.y = (beta[c] - s_mean * rg) * (1.f + sc) + sh;
         ab[(size_t)img * C + c] = o;
     }
 }
@@ -77,7 +80,7 @@ __global__ void film_kernel(const float* __restrict__ cond, const float* __restr
 void gn_finalize_launch(const float* d_stats, int nimg, int ntiles, int C, int hw, const float* d_gamma,
                         const float* d_beta, const float* d_film, int film_stride, int film_off,
                         float2* d_ab, hipStream_t stream) {
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(nimg), dim3(256), 0, stream, d_stats, ntiles, C, hw, d_gamma,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(nimg, 8), dim3(256), 0, stream, d_stats, ntiles, C, hw, d_gamma,
                        d_beta, d_film, film_stride, film_off, d_ab);
     IRE_HIP(hipGetLastError());
 }

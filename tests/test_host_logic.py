@@ -1,0 +1,189 @@
+"""Host-side mirrors of the reference services: same rules, names and error behaviour.
+Mirrors server-node/tests/promptEnhancerService.test.js and restoratorService.test.js."""
+import json
+import os
+
+import pytest
+
+from image_restoration_platform_amd import retry
+from image_restoration_platform_amd.prompt_enhancer import (KEYS, PromptEnhancerService, argmax_label,
+                                                            determine_severity, identify_top_issues)
+from image_restoration_platform_amd.restorator import RestoratorService
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BASE = {k: 0.1 for k in KEYS}
+
+
+class MockRestorer:
+    def __init__(self, fail=None):
+        self.calls = []
+        self.fail = fail
+
+    def restore_image(self, prompt, images, user_context=None):
+        self.calls.append({"prompt": prompt, "images": images, "user_context": user_context})
+        if self.fail:
+            raise self.fail
+        return {"base64Image": "ZmFrZS1kYXRh",
+                "metadata": {"providerRequestId": "req-123", "estimatedCostUsd": 0.12, "billedTokens": 512}}
+
+
+class MockClassifier:
+    def __init__(self, deg):
+        self.deg, self.calls = deg, []
+
+    def analyze(self, buf):
+        self.calls.append(buf)
+        return self.deg
+
+
+class MockEnhancer:
+    def __init__(self, text):
+        self.text, self.calls = text, []
+
+    def enhance(self, degradation, user_prompt=None, options=None):
+        self.calls.append({"degradation": degradation, "userPrompt": user_prompt, "options": options})
+        return self.text
+
+
+# ---- promptEnhancerService.test.js:16-58 -------------------------------------------------------
+def test_prioritizes_top_issues():
+    deg = {**BASE, "blur": 0.82, "noise": 0.81, "colorShift": 0.76, "fade": 0.55}
+    out = PromptEnhancerService().enhance(deg, "Repair and restore the family portrait")
+    assert "reduce severe motion blur" in out and "aggressively suppress grain" in out
+    assert "correct severe color cast" in out and "Repair and restore the family portrait" in out
+    assert "enhance color vibrancy" not in out     # fade is the 4th issue: capped at 3
+
+
+def test_subtle_enhancements_when_clean():
+    out = PromptEnhancerService().enhance(dict(BASE))
+    assert "Quality guidelines" in out and "subtle enhancements only" in out
+
+
+def test_truncation():
+    out = PromptEnhancerService().enhance({**BASE, "blur": 0.9}, "enhance " * 300)
+    assert len(out) <= 1000 and "User request:" in out and out.endswith("...") and len(out) == 953
+
+
+def test_ranking_rules():
+    assert determine_severity(0.7) == "high" and determine_severity(0.69999) == "medium"
+    assert determine_severity(0.5) == "medium" and determine_severity(0.49) == "low"
+    deg = {**BASE, "noise": 0.6, "blur": 0.6, "fade": 0.3, "scratch": 0.31}   # 0.3 is NOT > 0.3; ties keep key order
+    assert [i["type"] for i in identify_top_issues(deg)] == ["blur", "noise", "scratch"]
+    assert argmax_label({**BASE, "noise": 0.6, "blur": 0.6}) == "blur"          # first max wins
+    with pytest.raises(ValueError):
+        PromptEnhancerService.validate_degradation({**BASE, "blur": 1.5})
+    assert PromptEnhancerService.validate_degradation(dict(BASE))
+
+
+def test_prompt_part_order_and_unknown_type():
+    enh = PromptEnhancerService()
+    out = enh.enhance({**BASE, "blur": 0.9}, "  fix it  ")
+    assert out.index("User request: fix it.") < out.index("Technical restoration:") < out.index("Quality guidelines:")
+    assert out.endswith("apply corrections carefully to avoid artifacts.")
+    assert "address glare issues" in enh.enhance({**BASE, "glare": 0.8})
+
+
+def test_golden_prompts():
+    enh = PromptEnhancerService()
+    for c in json.load(open(os.path.join(HERE, "golden", "classifier_golden.json"))):
+        deg = {k: float.fromhex(v) for k, v in zip(KEYS, c["scores_hex"])}
+        assert enh.enhance(deg) == c["prompt"]
+        assert [[t["type"], t["severity"]] for t in identify_top_issues(deg)] == c["top_issues"]
+        assert argmax_label(deg) == c["label_name"] == KEYS[c["label"]]
+
+
+# ---- restoratorService.test.js:18-79 ------------------------------------------------------------
+DEG = {"blur": 0.6, "noise": 0.4, "lowLight": 0.2, "compression": 0.3, "scratch": 0.1, "fade": 0.2, "colorShift": 0.1}
+
+
+def test_full_workflow_and_metadata():
+    g = MockRestorer()
+    svc = RestoratorService(gemini_client=g)
+    svc.classifier = MockClassifier(DEG)
+    svc.prompt_enhancer = MockEnhancer("enhanced prompt")
+    buf = b"\xff\xd8fake"
+    r = svc.restore(buf, user_prompt="touch up blemishes", user_context={"userId": "user-123"})
+    assert svc.classifier.calls == [buf]
+    assert svc.prompt_enhancer.calls == [{"degradation": DEG, "userPrompt": "touch up blemishes", "options": {}}]
+    assert g.calls == [{"prompt": "enhanced prompt", "images": [buf], "user_context": {"userId": "user-123"}}]
+    assert r["success"] is True and r["restoredImage"] == "ZmFrZS1kYXRh"
+    assert r["metadata"]["providerRequestId"] == "req-123" and r["metadata"]["billedTokens"] == 512
+    assert r["metadata"]["classificationIssues"] == [{"type": "blur", "confidence": 0.6}, {"type": "noise", "confidence": 0.4}]
+    assert r["timings"]["classify_ms"] >= 0 and set(r["timings"]) == {"classify_ms", "prompt_ms", "restore_ms", "total_ms"}
+    assert r["degradationAnalysis"] == DEG and r["enhancedPrompt"] == "enhanced prompt"
+
+
+def test_structured_error_and_failure_stage_quirk():
+    svc = RestoratorService(gemini_client=MockRestorer(fail=RuntimeError("provider unavailable")))
+    svc.classifier = MockClassifier(DEG)
+    svc.prompt_enhancer = MockEnhancer("prompt")
+    r = svc.restore(b"x", user_context={"userId": "u"})
+    assert r["success"] is False
+    assert r["error"]["message"] == "provider unavailable" and r["error"]["code"] == "RESTORATION_FAILED"
+    assert r["metadata"]["failureStage"] == "CLASSIFICATION"   # 0 ms stages count as "not run" (restorator.js:270-284)
+
+
+def test_requires_client_and_error_classification():
+    with pytest.raises(ValueError):
+        RestoratorService()
+    ce = RestoratorService._classify_error
+    assert ce(Exception("Rate limit hit (429)")) == "RATE_LIMIT_EXCEEDED"
+    assert ce(Exception("timeout: job still pending")) == "TIMEOUT"
+    assert ce(Exception("invalid image size for restore")) == "INVALID_INPUT"
+    assert ce(Exception("401 unauthorized")) == "AUTHENTICATION_FAILED"
+    assert ce(Exception("service unavailable: no HIP device visible")) == "SERVICE_UNAVAILABLE"
+    assert ce(Exception("boom")) == "UNKNOWN_ERROR"
+    ds = RestoratorService._determine_failure_stage
+    assert ds({"classify_ms": 5}) == "PROMPT_ENHANCEMENT"
+    assert ds({"classify_ms": 5, "prompt_ms": 1}) == "AI_RESTORATION"
+    assert ds({}) == "CLASSIFICATION"
+    assert ds({"classify_ms": 5, "prompt_ms": 1, "restore_ms": 9}) == "UNKNOWN"
+
+
+def test_restore_batch_order_and_options():
+    g = MockRestorer()
+    svc = RestoratorService(gemini_client=g)
+    svc.classifier = MockClassifier(DEG)
+    svc.prompt_enhancer = MockEnhancer("p")
+    bufs = [bytes([i]) for i in range(7)]
+    rs = svc.restore_batch(bufs, user_prompt="x")
+    assert len(rs) == 7 and all(r["success"] for r in rs)
+    opts = sorted((c["options"]["batchIndex"], c["options"]["batchSize"]) for c in svc.prompt_enhancer.calls)
+    assert opts == [(i, 7) for i in range(7)]
+    assert sorted(c["images"][0] for c in g.calls) == bufs
+
+
+def test_engine_error_code_propagates():
+    from image_restoration_platform_amd.engine import EngineError
+    svc = RestoratorService(gemini_client=MockRestorer(fail=EngineError(3, "service unavailable: no HIP device visible")))
+    svc.classifier = MockClassifier(DEG)
+    r = svc.restore(b"x")
+    assert r["error"]["code"] == "ENGINE_UNAVAILABLE" and r["error"]["type"] == "SERVICE_UNAVAILABLE"
+
+
+# ---- retry.js / jobQueue.js -------------------------------------------------------------------------
+def test_exponential_backoff_policy():
+    delays, calls = [], []
+
+    def fn():
+        calls.append(1)
+        if len(calls) < 3:
+            raise RuntimeError("x")
+        return "ok"
+    out = retry.exponential_backoff(fn, rng=lambda: 0.5, sleep=lambda s: delays.append(s),
+                                    on_retry=lambda e, info: None)
+    assert out == "ok" and len(calls) == 3 and delays == [0.5, 1.0]   # 500 ms * 2^(n-1), jitter centred at rng=.5
+    assert retry.calculate_delay(500, 2, 2, 0.3, rng=lambda: 0.0) == pytest.approx(700.0)
+    assert retry.calculate_delay(500, 2, 2, 0.3, rng=lambda: 1.0) == pytest.approx(1300.0)
+    with pytest.raises(RuntimeError):
+        retry.exponential_backoff(lambda: (_ for _ in ()).throw(RuntimeError("always")), attempts=2, sleep=lambda s: None)
+    with pytest.raises(TypeError):
+        retry.exponential_backoff(None)
+
+
+def test_queue_backoff_policy():
+    assert retry.calculate_backoff(1, 1000, 0.3, rng=lambda: 0.5) == 1000
+    assert retry.calculate_backoff(3, 1000, 0.3, rng=lambda: 0.0) == 2800
+    assert retry.calculate_backoff(3, 1000, 0.3, rng=lambda: 1.0) == 5200
+    assert retry.calculate_backoff(0, 1000, 0.3, rng=lambda: 0.5) == 1000      # exponent clamps at 0
+    assert retry.QUEUE_DEFAULTS["name"] == "image-restoration-jobs" and retry.QUEUE_DEFAULTS["attempts"] == 5

@@ -1,0 +1,129 @@
+"""CPU tests of the classifier oracle (oracle/classifier_oracle.c) against the reference's own
+fixtures / known answers and the committed golden vectors."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from image_restoration_platform_amd import synth
+from oracle import classifier as oc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KEYS = oc.KEYS
+
+
+def _img_from_case(c):
+    h, w = c["size"][1], c["size"][0]
+    if "fill" in c:
+        img = np.zeros((h, w, 3), np.uint8)
+        img[:] = c["fill"]
+        return img
+    rng = np.random.default_rng(c["rng_seed"])
+    return rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+
+
+def test_known_answers_from_reference_fixtures():
+    """Analytic values worked out from classifier.js on imageFixtures.js:5-45 (not produced by this repo)."""
+    for c in json.load(open(os.path.join(HERE, "golden", "classifier_kat.json"))):
+        s, label = oc.classify(_img_from_case(c), c["is_jpeg"])
+        d = dict(zip(KEYS, s))
+        for k, v in c.get("expect", {}).items():
+            assert d[k] == pytest.approx(v, abs=1e-12), (c["name"], k, d[k], v)
+        for k, v in c.get("expect_min", {}).items():
+            assert d[k] >= v, (c["name"], k, d[k])
+        for k, v in c.get("expect_max", {}).items():
+            assert d[k] <= v, (c["name"], k, d[k])
+        if "label" in c:
+            assert KEYS[label] == c["label"]
+
+
+def test_reference_inequality_tests():
+    """server-node/tests/classifierService.test.js:19-57 on raw equivalents of its fixtures."""
+    flat = np.full((128, 128, 3), 180, np.uint8)
+    assert oc.classify(flat)[0][0] > 0.2                       # blurred (a blurred flat field is flat): blur > 0.2
+    noisy = np.random.default_rng(1234).integers(0, 256, (128, 128, 3), dtype=np.uint8)
+    assert oc.classify(noisy)[0][1] > 0.3                      # noise > 0.3
+    assert oc.classify(np.full((128, 128, 3), 10, np.uint8))[0][2] > 0.3   # lowLight > 0.3
+    cast = np.zeros((128, 128, 3), np.uint8); cast[:] = (220, 80, 40)
+    assert oc.classify(cast)[0][6] > 0.25                      # colorShift > 0.25
+    s = oc.classify(flat)[0]
+    assert np.all(s >= 0) and np.all(s <= 1)                   # clean: all in [0,1]
+
+
+def test_twopass_js_order_agrees_with_integer_form():
+    """classifier.js:262-266 evaluated literally (two sequential double passes) vs the exact
+    integer-sum form the GPU uses: <= 1e-9 relative, same label."""
+    for i in range(10):
+        h, w = [(64, 64), (37, 53), (128, 96), (17, 65), (200, 120)][i % 5]
+        img = synth.image(i, h, w)
+        for jp in (True, False):
+            a, la = oc.classify(img, jp)
+            b, lb = oc.classify(img, jp, twopass=True)
+            assert np.allclose(a, b, rtol=1e-9, atol=1e-12), (i, a, b)
+            assert la == lb
+
+
+def test_committed_golden_matches_oracle_bit_exactly():
+    for c in json.load(open(os.path.join(HERE, "golden", "classifier_golden.json"))):
+        img = synth.image(c["index"], c["h"], c["w"])
+        s, l, sums = oc.classify(img, bool(c["is_jpeg"]), with_sums=True)
+        assert [float(x).hex() for x in s] == c["scores_hex"], c["index"]
+        assert l == c["label"]
+        assert [int(x) for x in sums.as_list()] == c["sums"]
+
+
+def test_pixel_semantics_small_example():
+    """Edge-replicated borders, greyscale before convolve, saturating u8 cast (Appendix A.4-6)."""
+    g = np.array([[10, 10, 10, 10], [10, 200, 10, 10], [10, 10, 10, 10]], np.uint8)
+    img = np.repeat(g[:, :, None], 3, axis=2)  # R=G=B => grey == value (Appendix A.3)
+    p = oc.planes(img)
+    assert np.array_equal(p["grey"], g)
+    # Laplacian-8 at the spike: 8*200 - 8*10 = 1520 -> 255; neighbours: 8*10 - (7*10 + 200) = -190 -> 0
+    assert p["e8"][1, 1] == 255 and p["e8"][0, 0] == 0 and p["e8"][1, 2] == 0
+    # high-pass-9 on a flat area returns the pixel (9c - 8c): corner uses replicated border
+    assert p["e9"][2, 3] == 10
+    # Laplacian-4: 4*200 - 40 = 760 -> 255 ; 4-neighbour of the spike: 40 - (200 + 30) < 0 -> 0
+    assert p["e4"][1, 1] == 255 and p["e4"][0, 1] == 0
+    # sigma=1 integer gaussian {12,20,12}/44, two rounded passes: centre = round(round((12*10+20*200+12*10)/44) ...)
+    h1 = (12 * 10 + 20 * 200 + 12 * 10 + 22) // 44          # 96
+    v = (12 * 10 + 20 * h1 + 12 * 10 + 22) // 44            # rows above/below have hblur 10 at x=1? no: they are 10
+    assert p["blur"][1, 1, 0] == v
+
+
+def test_scratch_probe_semantics():
+    """classifier.js:316-333: stride-4 probes, right / below neighbour, bounds checks."""
+    img = np.zeros((8, 8, 3), np.uint8)
+    img[4:6, 4:6] = 255          # bright 2x2 block at the probe (4,4): Laplacian-4 = 4*255 - 2*255 = 510 -> 255 at all 4
+    s, _, sums = oc.classify(img, False, with_sums=True)
+    assert sums.scratch_v == 1 and sums.scratch_h == 1
+    assert s[4] == 2 / 1000.0
+
+
+def test_edge_shapes_and_invalid():
+    for h, w in [(1, 1), (1, 7), (9, 1), (3, 5), (4, 4)]:
+        img = synth.image(3, max(h, 8), max(w, 8))[:h, :w]
+        a, la = oc.classify(np.ascontiguousarray(img), True)
+        b, lb = oc.classify(np.ascontiguousarray(img), True, twopass=True)
+        assert a.shape == (7,) and la == lb
+        assert np.allclose(a, b, rtol=1e-9, atol=1e-12, equal_nan=True)   # 1x1: stdev = sqrt(0/0) = NaN as in JS
+    with pytest.raises(ValueError):
+        oc.classify(np.zeros((0, 4, 3), np.uint8))
+
+
+def test_grey_tables_match_product_inc():
+    """The engine's frozen tables (csrc/grey_tables.inc) equal the oracle's run-time tables."""
+    import re
+    txt = open(os.path.join(HERE, "..", "image_restoration_platform_amd", "csrc", "grey_tables.inc")).read()
+
+    def arr(name):
+        body = re.search(name + r"\[[^\]]*\] = \{([^}]*)\}", txt).group(1)
+        return np.array([int(x.strip().rstrip("u")) for x in body.split(",") if x.strip()], dtype=np.uint64)
+    lin, thr = oc.grey_tables()
+    assert np.array_equal(arr("kLin16"), lin.astype(np.uint64))
+    t = arr("kGreyThr")
+    assert np.array_equal(t[:256], thr.astype(np.uint64)) and t[256] == 0xFFFFFFFF
+    inv = arr("kGreyInv")
+    ys = (np.arange(len(inv), dtype=np.uint64) << np.uint64(17))
+    expect = np.searchsorted(thr.astype(np.uint64), ys, side="right") - 1
+    assert np.array_equal(inv, expect.astype(np.uint64))
