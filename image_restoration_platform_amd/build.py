@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "lib", "libire.so")
 SOURCES = [
     ("classifier.hip", ["-ffp-contract=off"]),
     ("conv_mfma.hip", []),
-    ("conv_rb.hip", []),
+    ("conv_rb.hip", ["-DIRE_RB_ABLATE"] if os.environ.get("IRE_RB_ABLATE") else []),
     ("gn.hip", []),
     ("fusion.hip", []),
     ("engine.cpp", []),

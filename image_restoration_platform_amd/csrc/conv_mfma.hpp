@@ -44,6 +44,9 @@ void conv_launch(ConvKind kind, const ConvArgs& a, hipStream_t stream);
 // Persistent software-pipelined variant for CONV_RB1 / CONV_RB2 (conv_rb.hip): 16x32 tiles
 // (a.tiles_y must be ceil(Hout/16)), same weight slab layout, same ConvArgs.
 constexpr int kRbTileH = 16;
-void conv_rb_launch(bool resid, const ConvArgs& a, hipStream_t stream);
+// fused_act: apply y = silu(x*A+B) while staging (a.ab); otherwise the input is already activated.
+void conv_rb_launch(bool resid, bool fused_act, const ConvArgs& a, hipStream_t stream);
+// CONV_UP through the same pipelined kernel (Hin/Win = low-res source, Hout/Wout = 2x; a.stats = nullptr).
+void conv_up_launch(const ConvArgs& a, hipStream_t stream);
 
 }  // namespace ire

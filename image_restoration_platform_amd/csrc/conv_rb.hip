@@ -17,6 +17,8 @@
 // Roofline: MFMA for C >= 128 (2*9*C*C flop per pixel), HBM for C = 32/64 (4C..6C B per pixel).
 #include "conv_mfma.hpp"
 
+#include <cstdlib>
+
 namespace ire {
 
 namespace {
@@ -31,7 +33,7 @@ constexpr int RB_THREADS = 512;
 constexpr int RB_TH = 16, RB_TW = 32;
 constexpr int RB_IH = RB_TH + 2, RB_IW = RB_TW + 2;
 constexpr int RB_IN_CHUNKS = RB_IH * RB_IW * 4;                                // 2448 x 16 B
-constexpr int RB_IN_BYTES = RB_IN_CHUNKS * 16;                                  // 39168
+constexpr int RB_IN_BYTES = 5 * RB_THREADS * 16;                               // 40960: padded so all 5x512 chunk slots exist
 constexpr int RB_IN_ITERS = (RB_IN_CHUNKS + RB_THREADS - 1) / RB_THREADS;       // 5
 constexpr int RB_NSTEPS = 18;
 
@@ -47,6 +49,14 @@ __device__ __forceinline__ float rb_silu(float y) {
     return y * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// LDS-DMA, 16 B per lane: LDS destination = wave-uniform byte address (through M0) + lane*16; the source is
+// per lane.  Not visible to the compiler's s_waitcnt bookkeeping: the caller waits (vmcnt) and barriers.
+__device__ __forceinline__ void rb_glds16(const void* gsrc, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+
 struct RbItem {
     int img, ty, tx, nb, tile;  // tile = ty*tiles_x + tx
 };
@@ -56,7 +66,7 @@ struct RbRegs {          // one prefetched input stage
     unsigned ok;         // bit it: chunk it is inside the image
 };
 
-template <int NT, bool RESID, bool WRES>
+template <int NT, bool RESID, bool WRES, bool FUSED_ACT>
 struct RbCfg {
     static constexpr int NTL = NT / 32;
     static constexpr int W_CHUNKS = RB_NSTEPS * 2 * NT;   // 16-B chunks per (n-block, k-chunk) slab
@@ -67,19 +77,24 @@ struct RbCfg {
     static constexpr int W_OFF0 = WRES ? 2 * RB_IN_BYTES : RB_IN_BYTES;
     static constexpr int MAIN_BYTES = WRES ? 2 * RB_IN_BYTES + W_BYTES : 2 * (RB_IN_BYTES + W_BYTES);
     static constexpr int RED_BYTES = 8 * (NT / 8) * 4 * 4;
-    static constexpr int LDS_BYTES = MAIN_BYTES + RED_BYTES;
+    static constexpr int COEF_BYTES = 2 * 256;              // two stages x 32 channels x (A,B) floats
+    static constexpr int BIAS_BYTES = 256 * 4;              // the layer's whole bias vector (cout <= 256)
+    static constexpr int LDS_BYTES = MAIN_BYTES + RED_BYTES + COEF_BYTES + BIAS_BYTES;
     static constexpr int OUT_ITERS = RB_TH * RB_TW * (NT / 8) / RB_THREADS;    // NT/8
     static_assert(RB_TH * RB_TW * NT * 2 <= BUF_STRIDE, "output tile must fit in one stage buffer");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int NT, bool RESID, bool WRES>
+// DBG (timing ablations only, results are wrong): 1 = no MFMA, 2 = no fragment reads + no MFMA,
+// 4 = no epilogue global traffic, 8 = no input global loads.
+template <int NT, bool RESID, bool WRES, bool FUSED_ACT, int DBG = 0, bool UPS = false>
 __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
-    using C = RbCfg<NT, RESID, WRES>;
+    using C = RbCfg<NT, RESID, WRES, FUSED_ACT>;
     constexpr int NTL = C::NTL;
     constexpr int NCC = NT / 8;
     __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
 
+    const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;   // LDS byte address
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -127,55 +142,86 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
     const int b_off = (h * NT + r) * 16;                           // + (2s*NT + j*32)*16
 
     // ---- helpers -------------------------------------------------------------------------------------
+    const int cin_shift = 31 - __builtin_clz(Cin);                 // Cin is a power of two
     auto load_stage = [&](int s, RbRegs& R) {
         const RbItem it = item_of(s / nkc);
         const int kc = s - (s / nkc) * nkc;
-        const int oy0 = it.ty * RB_TH, ox0 = it.tx * RB_TW;
-        const unsigned short* base = src + (size_t)it.img * a.Hin * a.Win * Cin + kc * 32 + c8_fixed * 8;
+        const int oy1 = it.ty * RB_TH - 1, ox1 = it.tx * RB_TW - 1;
+        // wave-uniform image base (SGPR pair) + 32-bit per-lane byte offset
+        const char* base = reinterpret_cast<const char*>(src) + (size_t)it.img * a.Hin * a.Win * Cin * 2 + kc * 64;
         R.ok = 0;
         int t2 = tid;
-        asm volatile("" : "+v"(t2));   // recompute the chunk index math per stage instead of keeping it live
+        asm volatile("" : "+v"(t2));   // recompute the halo coordinates per stage: cheaper than 5 live registers
 #pragma unroll
         for (int i = 0; i < RB_IN_ITERS; ++i) {
-            const int idx = t2 + i * RB_THREADS;
-            const int p = idx >> 2;
+            const int p = (t2 + i * RB_THREADS) >> 2;
             const int py = p / RB_IW, px = p - py * RB_IW;
-            const int iy = oy0 + py - 1, ix = ox0 + px - 1;
-            const bool ok = (idx < RB_IN_CHUNKS) && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-            const int cy = min(max(iy, 0), a.Hin - 1), cx = min(max(ix, 0), a.Win - 1);
-            R.v[i] = *reinterpret_cast<const uint4*>(base + ((size_t)cy * a.Win + cx) * Cin);  // always in bounds
+            const int iy = oy1 + py, ix = ox1 + px;
+            // UPS: the conv runs on the nearest-x2 upsampled grid (extent = output extent); source pixel = coord >> 1
+            const int HV = UPS ? a.Hout : a.Hin, WV = UPS ? a.Wout : a.Win;
+            const int cy = min(max(iy, 0), HV - 1), cx = min(max(ix, 0), WV - 1);
+            const bool ok = iy == cy && ix == cx;   // slots past the tile (py >= 18) land in the LDS padding
+            const int sy = UPS ? (cy >> 1) : cy, sx = UPS ? (cx >> 1) : cx;
+            const unsigned off = ((unsigned)(sy * a.Win + sx) << (cin_shift + 1)) + (unsigned)(c8_fixed * 16);
+            if constexpr (DBG & 8) R.v[i] = make_uint4(off, 0x3f803f80u, i, 0x3f803f80u);
+            else R.v[i] = *reinterpret_cast<const uint4*>(base + off);   // clamped: always in bounds
             R.ok |= ok ? (1u << i) : 0u;
         }
     };
-    auto load_coeffs = [&](int s, float (&cA)[8], float (&cB)[8]) {
-        const RbItem it = item_of(s / nkc);
-        const int kc = s - (s / nkc) * nkc;
-        const float4* ab = reinterpret_cast<const float4*>(a.ab + (size_t)it.img * Cin + kc * 32 + c8_fixed * 8);
+    // GroupNorm+FiLM coefficients travel global -> register (16 lanes, issued with the input prefetch so the
+    // same forced wait covers them) -> LDS slot -> every thread's 16 floats.  Keeping them off the VMEM queue
+    // at the stage top matters: vmcnt completes in order, so a late coefficient load would drag the previous
+    // item's output stores into the wait.
+    float* coef_lds = reinterpret_cast<float*>(smem + C::MAIN_BYTES + C::RED_BYTES);   // [2][32 ch][2]
+    auto fetch_coeffs = [&](int s) -> float4 {                   // lanes 0..15: 16 B each of the stage's 256 B
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (FUSED_ACT) {
+            const RbItem it = item_of(s / nkc);
+            const int kc = s - (s / nkc) * nkc;
+            const float4* ab = reinterpret_cast<const float4*>(a.ab + (size_t)it.img * Cin + kc * 32);
+            v = ab[tid & 15];
+        }
+        return v;
+    };
+    auto put_coeffs = [&](int slot, const float4& v) {
+        if constexpr (FUSED_ACT) { if (tid < 16) reinterpret_cast<float4*>(coef_lds + slot * 64)[tid] = v; }
+    };
+    auto load_coeffs = [&](int slot, float (&cA)[8], float (&cB)[8]) {
+        if constexpr (!FUSED_ACT) return;
+        const float4* ab = reinterpret_cast<const float4*>(coef_lds + slot * 64 + c8_fixed * 16);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float4 v = ab[e];
             cA[2 * e] = v.x; cB[2 * e] = v.y; cA[2 * e + 1] = v.z; cB[2 * e + 1] = v.w;
         }
     };
-    auto store_chunk = [&](int i, const RbRegs& R, const float (&cA)[8], const float (&cB)[8], uint4* lds_in) {
-        int t2 = tid;
-        asm volatile("" : "+v"(t2));
-        const int idx = t2 + i * RB_THREADS;
-        if (idx < RB_IN_CHUNKS) {
-            uint4 o = make_uint4(0, 0, 0, 0);          // zero padding applies AFTER the activation
-            if (R.ok & (1u << i)) {
-                unsigned w[4] = {R.v[i].x, R.v[i].y, R.v[i].z, R.v[i].w};
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const float y0 = __builtin_fmaf(rb_lo(w[d]), cA[2 * d], cB[2 * d]);
-                    const float y1 = __builtin_fmaf(rb_hi(w[d]), cA[2 * d + 1], cB[2 * d + 1]);
-                    w[d] = rb_pack(rb_silu(y0), rb_silu(y1));
-                }
-                o = make_uint4(w[0], w[1], w[2], w[3]);
-            }
-            const int p = idx >> 2;
-            lds_in[p * 4 + (c8_fixed ^ ((p >> 2) & 3))] = o;
+    // The s+1 transform is cut into 20 word-sized pieces (5 chunks x 4 words of 2 channels) so that one
+    // piece can follow every MFMA k-step: straight-line code, interleaved by source order.
+    auto word_of = [&](const uint4& v, int d) -> unsigned { return d == 0 ? v.x : d == 1 ? v.y : d == 2 ? v.z : v.w; };
+    auto transform_word = [&](unsigned w, int d, const float (&cA)[8], const float (&cB)[8]) -> unsigned {
+        if constexpr (FUSED_ACT) {
+            const float y0 = __builtin_fmaf(rb_lo(w), cA[2 * d], cB[2 * d]);
+            const float y1 = __builtin_fmaf(rb_hi(w), cA[2 * d + 1], cB[2 * d + 1]);
+            return rb_pack(rb_silu(y0), rb_silu(y1));
+        } else {
+            return w;                                  // input was activated by gn_apply_silu (gn.hip)
         }
+    };
+    auto store_words = [&](int i, const RbRegs& R, const unsigned (&tw)[4], uint4* lds_in) {
+        int t2 = tid;
+        asm volatile("" : "+v"(t2));   // recompute the LDS address per use instead of keeping 5 of them live
+        const int idx = t2 + i * RB_THREADS;
+        const bool ok = (R.ok >> i) & 1u;              // zero padding applies AFTER the activation
+        uint4 o;
+        o.x = ok ? tw[0] : 0u; o.y = ok ? tw[1] : 0u; o.z = ok ? tw[2] : 0u; o.w = ok ? tw[3] : 0u;
+        const int p = idx >> 2;
+        lds_in[p * 4 + (c8_fixed ^ ((p >> 2) & 3))] = o;
+    };
+    auto store_chunk = [&](int i, const RbRegs& R, const float (&cA)[8], const float (&cB)[8], uint4* lds_in) {
+        unsigned tw[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) tw[d] = transform_word(word_of(R.v[i], d), d, cA, cB);
+        store_words(i, R, tw, lds_in);
     };
     auto wslab = [&](int s) -> const uint4* {
         const RbItem it = item_of(s / nkc);
@@ -199,19 +245,24 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
     float* red = reinterpret_cast<float*>(smem + C::MAIN_BYTES);   // [8 waves][NCC][4]
     auto flush_stats = [&]() {
         if (st_img < 0) return;
+        if (a.stats == nullptr) { st_img = -1; return; }
         const int Gs = a.group_size, ngl = NT / Gs;
         if (tid < ngl) {
             float s = 0.f, q = 0.f;
-            if (Gs == 4) {
-                const int c = tid >> 1, half = tid & 1;
-                for (int w = 0; w < 8; ++w) { s += red[(w * NCC + c) * 4 + 2 * half]; q += red[(w * NCC + c) * 4 + 2 * half + 1]; }
-            } else {
-                const int cpg = Gs >> 3;
-                for (int w = 0; w < 8; ++w)
-                    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
-                        s += red[(w * NCC + c) * 4 + 0] + red[(w * NCC + c) * 4 + 2];
-                        q += red[(w * NCC + c) * 4 + 1] + red[(w * NCC + c) * 4 + 3];
-                    }
+            const int cpg = Gs >> 3;                       // 16-B chunks per group (0 when Gs == 4)
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                if (Gs == 4) {                             // chunk = two groups: (cc, half)
+                    const float* d = red + (w * NCC + (tid >> 1)) * 4 + 2 * (tid & 1);
+                    s += d[0]; q += d[1];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < cpg) {
+                            const float* d = red + (w * NCC + tid * cpg + k) * 4;
+                            s += d[0] + d[2]; q += d[1] + d[3];
+                        }
+                }
             }
             const int gg = (st_nb * NT) / Gs + tid;
             float* st = a.stats + (((size_t)st_img * tiles_per_img + st_tile) * 8 + gg) * 2;
@@ -230,52 +281,92 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         unsigned char* w_nxt = smem + C::W_OFF0 + (WRES ? 0 : (PAR ^ 1) * C::BUF_STRIDE);
         RbRegs& Rn = PAR ? R0 : R1;   // holds stage s+1 (loaded during stage s-1)
         RbRegs& Rf = PAR ? R1 : R0;   // free: receives stage s+2
-        const bool have1 = (s + 1 < S), have2 = (s + 2 < S);
+        // no branches in the stage body: the last stages redo harmless work on clamped stage indices
+        const int s1 = min(s + 1, S - 1), s2 = min(s + 2, S - 1);
 
-        // (1) coefficients of stage s+1, (2) its weight slab, (3) input prefetch of stage s+2 -- in this
-        // order so waiting for (1)/(2) never waits for (3) (VMEM returns in issue order)
-        float cA[8], cB[8];
-        if (have1) load_coeffs(s + 1, cA, cB);
-        u32x4_t wreg[C::W_ITERS];
-        if constexpr (!WRES) {   // unconditional (clamped) so the array stays in registers
-            const u32x4_t* ws = reinterpret_cast<const u32x4_t*>(wslab(have1 ? s + 1 : s));
+        // (1) coefficients of stage s+1 first, then (3) the input prefetch of stage s+2, so that waiting
+        // for (1) never waits for (3) (VMEM returns in issue order)
+        // Rn was retired at the end of the previous stage (or of the prologue); say so on every path into the
+        // stage, so no wait on it is placed after the weight DMA below (where it would be a vmcnt(0)).
 #pragma unroll
-            for (int i = 0; i < C::W_ITERS; ++i) {
-                const int idx = tid + i * RB_THREADS;
-                wreg[i] = ws[idx < C::W_CHUNKS ? idx : 0];
-            }
-        }
-        if (have2) load_stage(s + 2, Rf);
+        for (int i = 0; i < RB_IN_ITERS; ++i) asm volatile("" : "+v"(Rn.v[i].x), "+v"(Rn.v[i].y), "+v"(Rn.v[i].z), "+v"(Rn.v[i].w));
+        float cA[8], cB[8];
+        load_coeffs(s & 1, cA, cB);                 // coefficients of stage s+1's data (slot written last stage)
+        float4 cnext = fetch_coeffs(s2);            // for the data of stage s+2, transformed during stage s+1
+        load_stage(s2, Rf);
 
+        if (s - (s / nkc) * nkc == 0) zero_acc();   // new item (not in the epilogue: 64 dead registers there)
         // (4) 18 MFMA k-steps from the current buffer, the s+1 transform interleaved between groups
         const int wsel = WRES ? ((s - (s / nkc) * nkc) * C::W_BYTES) : 0;   // resident: slab of this kc
         const unsigned char* wb = w_cur + wsel + b_off;
         const unsigned char* ib = reinterpret_cast<const unsigned char*>(in_cur);
-#pragma unroll
-        for (int st = 0; st < RB_NSTEPS; ++st) {
-            const int tap = st >> 1;
-            bf16x8_t bfrag[NTL], afrag[2];
-#pragma unroll
-            for (int j = 0; j < NTL; ++j)
-                bfrag[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wb + (2 * st * NT + j * 32) * 16));
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-                afrag[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ib + (a_off[m][tap] ^ ((st & 1) << 5))));
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
+        unsigned tw[4];
+        // Fragment reads are software-pipelined by hand: step st+1's four ds_read_b128 are issued before step
+        // st's four MFMAs, then one piece of the s+1 transform; a sched_barrier per step keeps that order (and the
+        // register budget: without it the scheduler hoists far ahead and spills).
+        bf16x8_t bfr[2][NTL], afr[2][2];
+        auto read_frags = [&](int st, bf16x8_t (&bf)[NTL], bf16x8_t (&af)[2]) {
+            if constexpr (!(DBG & 2)) {
+                const int tap = st >> 1;
 #pragma unroll
                 for (int j = 0; j < NTL; ++j)
-                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[m], bfrag[j], acc[m][j], 0, 0, 0);
-            if (have1 && (st % 3) == 2 && (st / 3) < RB_IN_ITERS) store_chunk(st / 3, Rn, cA, cB, in_nxt);
-        }
-        // (5) weight slab of stage s+1 -> other buffer
-        if constexpr (!WRES) {
+                    bf[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wb + (2 * st * NT + j * 32) * 16));
 #pragma unroll
-            for (int i = 0; i < C::W_ITERS; ++i) {
-                const int idx = tid + i * RB_THREADS;
-                if (idx < C::W_CHUNKS) reinterpret_cast<u32x4_t*>(w_nxt)[idx] = wreg[i];
+                for (int m = 0; m < 2; ++m)
+                    af[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ib + (a_off[m][tap] ^ ((st & 1) << 5))));
             }
+        };
+        read_frags(0, bfr[0], afr[0]);
+#pragma unroll
+        for (int st = 0; st < RB_NSTEPS; ++st) {
+            if (st + 1 < RB_NSTEPS) read_frags(st + 1, bfr[(st + 1) & 1], afr[(st + 1) & 1]);
+            if constexpr (!(DBG & 3)) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j)
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[st & 1][j], afr[st & 1][m], acc[m][j], 0, 0, 0);  // D[cout][pixel]
+            } else if constexpr (!(DBG & 2)) {
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) asm volatile("" :: "v"(bfr[st & 1][j]));   // keep the reads alive
+#pragma unroll
+                for (int m = 0; m < 2; ++m) asm volatile("" :: "v"(afr[st & 1][m]));
+            }
+            {   // piece st of the s+1 transform (chunk st>>2, word st&3)
+                tw[st & 3] = transform_word(word_of(Rn.v[st >> 2], st & 3), st & 3, cA, cB);
+                if ((st & 3) == 3) store_words(st >> 2, Rn, tw, in_nxt);
+            }
+            if constexpr (!WRES) {
+                // (2) weight slab of stage s+1 by LDS-DMA (global_load_lds_dwordx4: 16 B per lane, no registers), a
+                // pure copy into the OTHER buffer, 17 k-steps ahead of the end-of-stage wait + barrier that publish
+                // it.  Inline asm on purpose: with the builtin hipcc orders every later ds_write after the DMA with
+                // a vmcnt(0) (same LDS array => may alias), which would also drain the s+2 input prefetch.
+                if (st == 0) {
+                    const unsigned char* ws = reinterpret_cast<const unsigned char*>(wslab(s1));
+                    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+                    const unsigned w_nxt_lds = smem_lds + (unsigned)(w_nxt - smem);
+#pragma unroll
+                    for (int i = 0; i < C::W_ITERS; ++i) {
+                        const int cbase = i * RB_THREADS + wave_u * 64;          // first chunk of this wave-instruction
+                        if (cbase < C::W_CHUNKS)                                 // wave-uniform
+                            rb_glds16(ws + (size_t)(cbase + lane) * 16, w_nxt_lds + cbase * 16);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        tw[2] = transform_word(word_of(Rn.v[4], 2), 2, cA, cB);   // pieces 18, 19: the (partial) fifth chunk
+        tw[3] = transform_word(word_of(Rn.v[4], 3), 3, cA, cB);
+        store_words(4, Rn, tw, in_nxt);
+        // The s+2 prefetch has had a whole stage to land: retire it NOW (it is the oldest thing in this wave's
+        // in-order VMEM queue), so that no later wait -- in particular the next stage's first use of these
+        // registers, which on the epilogue path comes after 8 output stores -- has to drain anything newer.
+#pragma unroll
+        for (int i = 0; i < RB_IN_ITERS; ++i) asm volatile("" : "+v"(Rf.v[i].x), "+v"(Rf.v[i].y), "+v"(Rf.v[i].z), "+v"(Rf.v[i].w));
+        asm volatile("" : "+v"(cnext.x), "+v"(cnext.y), "+v"(cnext.z), "+v"(cnext.w));
+        put_coeffs((s + 1) & 1, cnext);
+        // (5) the DMA'd weight slab must have landed before the stage barrier publishes it
+        if constexpr (!WRES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // (6) last k-chunk of the item: epilogue through the current buffer
         const int kc = s - (s / nkc) * nkc;
         if (kc == nkc - 1) {
@@ -284,47 +375,76 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
             const int cout0 = it.nb * NT;
             __syncthreads();                                   // every wave is done reading buf[cur]
             flush_stats();                                     // (red[] of the previous item is complete)
-            unsigned short* lds_o = reinterpret_cast<unsigned short*>(smem + PAR * C::BUF_STRIDE);  // [512 px][NT]
+            // out tile [512 px][NT] bf16 in buf[cur]; 16-B chunk cc of pixel p lives at chunk cc ^ (p & (NCC-1)).
+            // accumulator i of lane (r = pixel column, h) is cout j*32 + 8*(i>>2) + 4h + (i&3): 4 consecutive
+            // couts -> one 8-byte LDS write.
+            unsigned char* lds_ob = smem + PAR * C::BUF_STRIDE;
+            int r_e = r, h_e = h;
+            asm volatile("" : "+v"(r_e), "+v"(h_e));
 #pragma unroll
             for (int j = 0; j < NTL; ++j) {
-                const float bias = a.bias[cout0 + j * 32 + r];
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int q = 0; q < 4; ++q) {
+                    const float4 bv = *reinterpret_cast<const float4*>(
+                        reinterpret_cast<const float*>(smem + C::MAIN_BYTES + C::RED_BYTES + C::COEF_BYTES) + cout0 + j * 32 + 8 * q + 4 * h_e);
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int x = (i & 3) + 8 * (i >> 2) + 4 * h;
-                        lds_o[((wave * 2 + m) * RB_TW + x) * NT + j * 32 + r] =
-                            (unsigned short)(rb_pack(acc[m][j][i] + bias, 0.f) & 0xffffu);
+                    for (int m = 0; m < 2; ++m) {
+                        const int pix = (wave * 2 + m) * RB_TW + r_e;
+                        const int cc = j * 4 + q;                     // 16-B chunk holding couts 8q..8q+7 of n-tile j
+                        uint2 v;
+                        v.x = rb_pack(acc[m][j][4 * q + 0] + bv.x, acc[m][j][4 * q + 1] + bv.y);
+                        v.y = rb_pack(acc[m][j][4 * q + 2] + bv.z, acc[m][j][4 * q + 3] + bv.w);
+                        *reinterpret_cast<uint2*>(lds_ob + (pix * NCC + (cc ^ (pix & (NCC - 1)))) * 16 + h_e * 8) = v;
                     }
+                }
             }
-            zero_acc();
+            // the accumulators are dead until the next item zeroes them: tell the register allocator
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) asm volatile("" : "=v"(acc[m][j]));
+            int te = tid;
+            asm volatile("" : "+v"(te));   // epilogue index math recomputed here (hoisted copies were spilled to scratch)
+            const int cc = te % NCC;
+            // residual tile: all loads issued together, addresses clamped into the image (stores are predicated)
+            uint4 rv[C::OUT_ITERS];
+            if constexpr (RESID && !(DBG & 4)) {
+#pragma unroll
+                for (int k = 0; k < C::OUT_ITERS; ++k) {
+                    const int pix = (te + k * RB_THREADS) / NCC;
+                    const int oy = min(oy0 + (pix >> 5), a.Hout - 1), ox = min(ox0 + (pix & 31), a.Wout - 1);
+                    const size_t g = (((size_t)it.img * a.Hout + oy) * a.Wout + ox) * a.cout + cout0 + cc * 8;
+                    rv[k] = *reinterpret_cast<const uint4*>(a.resid + g);
+                }
+            }
             __syncthreads();
-            const int cc = tid % NCC;
             float sA = 0.f, qA = 0.f, sB = 0.f, qB = 0.f;
-            const uint4* lds_o4 = reinterpret_cast<const uint4*>(lds_o);
+            const uint4* lds_o4 = reinterpret_cast<const uint4*>(lds_ob);
 #pragma unroll
             for (int k = 0; k < C::OUT_ITERS; ++k) {
-                const int idx = tid + k * RB_THREADS;
+                const int idx = te + k * RB_THREADS;
                 const int pix = idx / NCC;
                 const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
-                if (oy < a.Hout && ox < a.Wout) {
-                    const uint4 o = lds_o4[idx];
-                    const size_t g = (((size_t)it.img * a.Hout + oy) * a.Wout + ox) * a.cout + cout0 + cc * 8;
-                    unsigned w[4] = {o.x, o.y, o.z, o.w};
-                    if constexpr (RESID) {
-                        const uint4 rv = *reinterpret_cast<const uint4*>(a.resid + g);
-                        const unsigned rw[4] = {rv.x, rv.y, rv.z, rv.w};
+                const bool inb = oy < a.Hout && ox < a.Wout;
+                const uint4 o = lds_o4[pix * NCC + (cc ^ (pix & (NCC - 1)))];
+                const size_t g = (((size_t)it.img * a.Hout + oy) * a.Wout + ox) * a.cout + cout0 + cc * 8;
+                unsigned w[4] = {o.x, o.y, o.z, o.w};
+                if constexpr (RESID && !(DBG & 4)) {
+                    const unsigned rw[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w};
 #pragma unroll
-                        for (int d = 0; d < 4; ++d)
-                            w[d] = rb_pack(rb_lo(w[d]) + rb_lo(rw[d]), rb_hi(w[d]) + rb_hi(rw[d]));
-                    }
+                    for (int d = 0; d < 4; ++d)
+                        w[d] = rb_pack(rb_lo(w[d]) + rb_lo(rw[d]), rb_hi(w[d]) + rb_hi(rw[d]));
+                }
+                const float msk = inb ? 1.f : 0.f;           // out-of-image pixels do not count in the statistics
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        const float f0 = rb_lo(w[d]), f1 = rb_hi(w[d]);
-                        if (d < 2) { sA += f0 + f1; qA += f0 * f0 + f1 * f1; }
-                        else { sB += f0 + f1; qB += f0 * f0 + f1 * f1; }
-                    }
-                    *reinterpret_cast<uint4*>(a.out + g) = make_uint4(w[0], w[1], w[2], w[3]);
+                for (int d = 0; d < 4; ++d) {
+                    const float f0 = rb_lo(w[d]) * msk, f1 = rb_hi(w[d]) * msk;
+                    if (d < 2) { sA += f0 + f1; qA += f0 * f0 + f1 * f1; }
+                    else { sB += f0 + f1; qB += f0 * f0 + f1 * f1; }
+                }
+                if (inb) {
+                    if constexpr (DBG & 4) { if (w[0] == 0x12345678u) a.out[g] = 1; }
+                    else *reinterpret_cast<uint4*>(a.out + g) = make_uint4(w[0], w[1], w[2], w[3]);
                 }
             }
 #pragma unroll
@@ -344,8 +464,9 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
 
     // ---- prologue: stage 0 into buffer 0, stage 1 into registers --------------------------------------
     {
-        float cA[8], cB[8];
-        load_coeffs(0, cA, cB);
+        float* bias_lds = reinterpret_cast<float*>(smem + C::MAIN_BYTES + C::RED_BYTES + C::COEF_BYTES);
+        if (tid < a.cout) bias_lds[tid] = a.bias[tid];         // off the VMEM queue for good
+        put_coeffs(1, fetch_coeffs(0));                       // slot 1 plays "stage -1": transform of stage 0's data
         load_stage(0, R0);
         if (WRES) {   // whole weight set of this n-block stays in LDS (nblocks == 1)
             const uint4* ws = reinterpret_cast<const uint4*>(a.w);
@@ -356,10 +477,14 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
             uint4* wd = reinterpret_cast<uint4*>(smem + C::W_OFF0);
             for (int i = tid; i < C::W_CHUNKS; i += RB_THREADS) wd[i] = ws[i];
         }
+        __syncthreads();
+        float cA[8], cB[8];
+        load_coeffs(1, cA, cB);
         uint4* in0 = reinterpret_cast<uint4*>(smem);
 #pragma unroll
         for (int i = 0; i < RB_IN_ITERS; ++i) store_chunk(i, R0, cA, cB, in0);
-        if (S > 1) load_stage(1, R1);
+        put_coeffs(0, fetch_coeffs(min(1, S - 1)));           // slot 0: read at the top of stage 0 for stage 1's data
+        load_stage(min(1, S - 1), R1);
     }
     __syncthreads();
 
@@ -370,25 +495,50 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
     flush_stats();
 }
 
-template <int NT, bool RESID, bool WRES>
+template <int NT, bool RESID, bool WRES, bool FUSED_ACT, int DBG = 0, bool UPS = false>
 void launch_rb(const ConvArgs& a, hipStream_t stream) {
     const int items = a.tiles_x * a.tiles_y * a.nimg * a.nblocks;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int grid = items < cus ? items : cus;
-    hipLaunchKernelGGL((conv_rb_kernel<NT, RESID, WRES>), dim3(grid), dim3(RB_THREADS), 0, stream, a);
+    hipLaunchKernelGGL((conv_rb_kernel<NT, RESID, WRES, FUSED_ACT, DBG, UPS>), dim3(grid), dim3(RB_THREADS), 0, stream, a);
     IRE_HIP(hipGetLastError());
+}
+
+template <int DBG>
+void rb_dispatch(bool resid, bool fused_act, const ConvArgs& a, hipStream_t stream) {
+    if (a.cout == 32) {
+        if (resid) launch_rb<32, true, true, true, DBG>(a, stream); else launch_rb<32, false, true, true, DBG>(a, stream);
+    } else if (fused_act) {
+        if (resid) launch_rb<64, true, false, true, DBG>(a, stream); else launch_rb<64, false, false, true, DBG>(a, stream);
+    } else {
+        if (resid) launch_rb<64, true, false, false, DBG>(a, stream); else launch_rb<64, false, false, false, DBG>(a, stream);
+    }
 }
 
 }  // namespace
 
-void conv_rb_launch(bool resid, const ConvArgs& a, hipStream_t stream) {
-    if (a.cout == 32) {
-        if (resid) launch_rb<32, true, true>(a, stream); else launch_rb<32, false, true>(a, stream);
-    } else {
-        if (resid) launch_rb<64, true, false>(a, stream); else launch_rb<64, false, false>(a, stream);
+void conv_up_launch(const ConvArgs& a, hipStream_t stream) {
+    // nearest x2 -> conv3x3 (2C -> C): weights streamed (nkc >= 2), no prologue, no residual, no statistics
+    if (a.cout == 32) launch_rb<32, false, false, false, 0, true>(a, stream);
+    else launch_rb<64, false, false, false, 0, true>(a, stream);
+}
+
+void conv_rb_launch(bool resid, bool fused_act, const ConvArgs& a, hipStream_t stream) {
+#ifdef IRE_RB_ABLATE
+    static const int dbg = std::getenv("IRE_RB_DEBUG") ? std::atoi(std::getenv("IRE_RB_DEBUG")) : 0;
+    switch (dbg) {
+        case 1: return rb_dispatch<1>(resid, fused_act, a, stream);
+        case 2: return rb_dispatch<2>(resid, fused_act, a, stream);
+        case 4: return rb_dispatch<4>(resid, fused_act, a, stream);
+        case 8: return rb_dispatch<8>(resid, fused_act, a, stream);
+        case 6: return rb_dispatch<6>(resid, fused_act, a, stream);
+        case 14: return rb_dispatch<14>(resid, fused_act, a, stream);
+        default: break;
     }
+#endif
+    rb_dispatch<0>(resid, fused_act, a, stream);
 }
 
 }  // namespace ire

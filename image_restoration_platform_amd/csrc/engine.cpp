@@ -55,6 +55,7 @@ Engine::Engine(const ire_config& cfg) {
     if (num_lanes_ > 16) num_lanes_ = 16;
     flags_ = cfg.flags;
     if (const char* v = std::getenv("IRE_CONV_V1")) rb_tile_h_ = (v[0] == '1') ? 8 : kRbTileH;
+    if (const char* v = std::getenv("IRE_ACT_SPLIT_MINC")) act_split_min_c_ = std::atoi(v);
 
     IRE_HIP(hipStreamCreateWithFlags(&main_stream_, hipStreamNonBlocking));
     for (auto& ev : ev_) IRE_HIP(hipEventCreate(&ev));
@@ -292,6 +293,7 @@ void Engine::free_workspace() {
     for (auto& L : lanes_) {
         std::memset(L.act, 0, sizeof(L.act));
         std::memset(L.skip, 0, sizeof(L.skip));
+        std::memset(L.actbuf, 0, sizeof(L.actbuf));
         L.stats = nullptr;
         L.ab = nullptr;
     }
@@ -309,6 +311,7 @@ void Engine::ensure_workspace(int n, int h, int w) {
             const size_t bytes = (size_t)per * (h >> l) * (w >> l) * kWidths[l] * 2;
             for (int b = 0; b < 4; ++b) { L.act[l][b] = (unsigned short*)dalloc(bytes); ws_allocs_.push_back(L.act[l][b]); }
             if (l < 3) { L.skip[l] = (unsigned short*)dalloc(bytes); ws_allocs_.push_back(L.skip[l]); }
+            if (kWidths[l] >= act_split_min_c_) { L.actbuf[l] = (unsigned short*)dalloc(bytes); ws_allocs_.push_back(L.actbuf[l]); }
         }
         const size_t tiles0 = (size_t)ceil_div(h, 4) * ceil_div(w, 32);
         L.stats = (float*)dalloc((size_t)per * tiles0 * 16 * 4);
@@ -409,7 +412,9 @@ void Engine::launch_conv(Lane& L, const ConvW& cw, const void* in0, const void* 
     a.cout = (cw.kind == CONV_HEAD) ? 32 : cw.cout;
     a.tiles_x = ceil_div(Wout, 32);
     const bool rb = (cw.kind == CONV_RB1 || cw.kind == CONV_RB2);
-    a.tiles_y = ceil_div(Hout, rb ? rb_tile_h_ : conv_tile_h(cw.kind));
+    const bool up_rb = (cw.kind == CONV_UP) && rb_tile_h_ == kRbTileH;
+    a.tiles_y = ceil_div(Hout, (rb || up_rb) ? rb_tile_h_ : conv_tile_h(cw.kind));
+    if (up_rb) a.stats = nullptr;
     a.nimg = nimg; a.nblocks = cw.nblocks;
     a.group_size = std::max(1, a.cout / 8);
     const int taps = (cw.kind == CONV_FUSE) ? 1 : 9;
@@ -424,7 +429,8 @@ void Engine::launch_conv(Lane& L, const ConvW& cw, const void* in0, const void* 
     else if (cw.kind == CONV_STEM) fam = FAM_STEM;
     else if (cw.kind == CONV_HEAD) fam = FAM_HEAD;
     prof_begin(fam, L.stream, flops, bytes);
-    if (rb && rb_tile_h_ == kRbTileH) conv_rb_launch(cw.kind == CONV_RB2, a, L.stream);
+    if (up_rb) conv_up_launch(a, L.stream);
+    else if (rb && rb_tile_h_ == kRbTileH) conv_rb_launch(cw.kind == CONV_RB2, /*fused_act=*/ab != nullptr, a, L.stream);
     else conv_launch(cw.kind, a, L.stream);
     prof_end(L.stream);
     if (capture_ && cap_name && out) capture(cap_name, out, (size_t)nimg * Hout * Wout * cw.cout, L.stream);
@@ -443,12 +449,27 @@ void Engine::run_network(Lane& L, int nimg, int h, int w, const uint8_t* d_in, u
     // stats of out are in L.stats on exit.
     auto resblock = [&](const RBW& rb, const unsigned short* x, unsigned short* tmp, unsigned short* out, int l,
                         int x_tiles, const std::string& name) {
-        const int Ht = h >> l, Wt = w >> l;
+        const int Ht = h >> l, Wt = w >> l, C = kWidths[l];
+        const bool split = (rb_tile_h_ == kRbTileH) && C >= act_split_min_c_;   // activation as its own pass
         launch_gn(L, rb.gn1, nimg, Ht, Wt, x_tiles, d_film);
-        launch_conv(L, rb.conv1, x, nullptr, L.ab, nullptr, tmp, nullptr, nullptr, nimg, Ht, Wt, Ht, Wt,
+        const unsigned short* in1 = x;
+        if (split) {
+            prof_begin(FAM_GN, L.stream, 0, 2.0 * nimg * Ht * Wt * C * 2);
+            gn_apply_silu_launch(x, L.ab, L.actbuf[l], nimg, Ht * Wt, C, L.stream);
+            prof_end(L.stream);
+            in1 = L.actbuf[l];
+        }
+        launch_conv(L, rb.conv1, in1, nullptr, split ? nullptr : L.ab, nullptr, tmp, nullptr, nullptr, nimg, Ht, Wt, Ht, Wt,
                     capture_ ? (name + ".h").c_str() : nullptr);
         launch_gn(L, rb.gn2, nimg, Ht, Wt, tiles(Ht, Wt, rb_tile_h_), d_film);
-        launch_conv(L, rb.conv2, tmp, nullptr, L.ab, x, out, nullptr, nullptr, nimg, Ht, Wt, Ht, Wt,
+        const unsigned short* in2 = tmp;
+        if (split) {   // h is only ever read through GN2+SiLU: activate into the spare buffer (capture keeps raw h)
+            prof_begin(FAM_GN, L.stream, 0, 2.0 * nimg * Ht * Wt * C * 2);
+            gn_apply_silu_launch(tmp, L.ab, L.actbuf[l], nimg, Ht * Wt, C, L.stream);
+            prof_end(L.stream);
+            in2 = L.actbuf[l];
+        }
+        launch_conv(L, rb.conv2, in2, nullptr, split ? nullptr : L.ab, x, out, nullptr, nullptr, nimg, Ht, Wt, Ht, Wt,
                     capture_ ? name.c_str() : nullptr);
     };
 

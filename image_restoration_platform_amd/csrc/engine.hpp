@@ -53,6 +53,7 @@ struct Lane {
     hipEvent_t done = nullptr;
     unsigned short* act[4][4] = {};
     unsigned short* skip[3] = {};
+    unsigned short* actbuf[4] = {};   // activated copy of a ResBlock conv input (levels with C >= act_split_min_c)
     float* stats = nullptr;
     float2* ab = nullptr;
 };
@@ -115,6 +116,7 @@ private:
     int max_batch_ = 8;
     int num_lanes_ = 1;
     uint32_t flags_ = 0;
+    int act_split_min_c_ = 128;  // ResBlock convs with C >= this read a pre-activated tensor (gn_apply_silu)
     int rb_tile_h_ = kRbTileH;  // 16: persistent pipelined conv_rb.hip; 8: conv_mfma.hip (IRE_CONV_V1=1)
     std::mutex mu_;
     hipStream_t main_stream_ = nullptr;
