@@ -86,7 +86,7 @@ Engine::~Engine() {
     for (void* p : net_.allocs) (void)hipFree(p);
     for (void* p : table_allocs_) (void)hipFree(p);
     for (void* p : {(void*)d_in_, (void*)d_out_, (void*)d_jpeg_, (void*)d_sums_, (void*)d_scores_, (void*)d_label_,
-                    (void*)d_cond_, (void*)d_film_})
+                    (void*)d_cond_, (void*)d_film_, (void*)d_fL_, (void*)d_fQ_, (void*)d_fsad_, (void*)d_fmisc_})
         if (p) (void)hipFree(p);
     for (auto& L : lanes_) {
         if (L.stream) (void)hipStreamDestroy(L.stream);
@@ -270,7 +270,7 @@ void Engine::ensure_io(int n, int h, int w) {
     const size_t px = (size_t)h * w;
     if ((size_t)n <= io_cap_imgs_ && px <= io_cap_px_) return;
     IRE_HIP(hipDeviceSynchronize());
-    const size_t imgs = std::max<size_t>(io_cap_imgs_, (size_t)max_batch_);
+    const size_t imgs = std::max<size_t>(std::max<size_t>(io_cap_imgs_, (size_t)max_batch_), (size_t)n);
     const size_t cap_px = std::max(io_cap_px_, px);
     for (void* p : {(void*)d_in_, (void*)d_out_, (void*)d_jpeg_, (void*)d_sums_, (void*)d_scores_, (void*)d_label_,
                     (void*)d_cond_, (void*)d_film_})

@@ -83,6 +83,13 @@ public:
     void restore_device(const uint8_t* d_rgb, int n, int h, int w, const double* d_scores,
                         const uint8_t* d_is_jpeg, uint8_t* d_out, hipStream_t stream);
 
+    // fusion (fusion.hip)
+    void fuse_launch(const uint8_t* d_views, int k, int h, int w, const unsigned* host_wlut, uint8_t* d_out,
+                     int32_t* d_shifts, hipStream_t s);
+    double noise_of_view0(const uint8_t* d_views, int h, int w, hipStream_t s);
+    void fuse_host_impl(const uint8_t* rgb_views, int k, int h, int w, double noise_score, uint8_t* out_rgb,
+                        int32_t* shifts_out, ire_timings* t);
+
     void debug_sums(int n, uint64_t* out);
     void debug_capture(bool on) { capture_ = on; captured_.clear(); }
     bool debug_activation(const std::string& name, float* out, size_t* count);
@@ -138,6 +145,12 @@ private:
     float* d_cond_ = nullptr;
     float* d_film_ = nullptr;
     int last_n_ = 0;
+    // fusion scratch
+    size_t fuse_cap_px_ = 0;
+    uint8_t* d_fL_ = nullptr;
+    uint8_t* d_fQ_ = nullptr;
+    unsigned* d_fsad_ = nullptr;
+    int* d_fmisc_ = nullptr;
 
     // network
     Net net_;

@@ -1,0 +1,68 @@
+"""GPU parity of Fusion-v0 (build-defined, PARITY UNPINNED vs the reference) against oracle/fusion.py:
+integer algorithm => bit-exact shifts and pixels."""
+import numpy as np
+import pytest
+
+from image_restoration_platform_amd import synth
+from oracle import classifier as oc
+from oracle import fusion as ofu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("h,w,shifts", [
+    (128, 160, ((0, 0), (5, -3), (-4, 6))),          # SURVEY.md 8(d) shifts
+    (96, 96, ((0, 0), (-16, 15))),                   # two views, near the +-16 coarse limit
+    (256, 256, ((0, 0), (0, 0), (1, -1))),
+    (64, 64, ((0, 0), (2, 2), (-3, 1))),             # minimum size
+])
+def test_bit_exact_vs_oracle(engine, h, w, shifts):
+    views = synth.fusion_views(h, w, shifts=shifts)
+    for noise in (0.0, 0.37, 1.0):
+        out, sh = engine.fuse(views, noise_score=noise)
+        ref, rsh = ofu.fuse(views, noise)
+        assert np.array_equal(sh, rsh), (sh, rsh)
+        assert np.array_equal(out, ref), int(np.abs(out.astype(int) - ref.astype(int)).max())
+    assert np.array_equal(sh, np.array(shifts, np.int32))            # recovers the synthetic shifts
+
+
+def test_fusion_reduces_noise(engine):
+    views = synth.fusion_views(256, 256, noise_sigma=12.0)
+    clean = synth.fusion_views(256, 256, noise_sigma=0.0)[0]
+    out, _ = engine.fuse(views, noise_score=0.5)
+    err1 = np.abs(views[0].astype(int) - clean.astype(int))[32:-32, 32:-32].mean()
+    err3 = np.abs(out.astype(int) - clean.astype(int))[32:-32, 32:-32].mean()
+    assert err3 < 0.75 * err1
+
+
+def test_flat_views_tie_break_and_classify_inside(engine):
+    flat = np.full((3, 64, 64, 3), 90, np.uint8)
+    out, sh = engine.fuse(flat, noise_score=0.2)
+    assert np.array_equal(sh, np.zeros((3, 2), np.int32)) and np.array_equal(out, flat[0])
+    views = synth.fusion_views(128, 128)
+    noise = oc.classify(views[0], True)[0][1]                       # classifier's noise score of view 0
+    a, _ = engine.fuse(views, noise_score=-1.0)                     # engine classifies view 0 itself
+    b, _ = engine.fuse(views, noise_score=float(noise))
+    assert np.array_equal(a, b)
+
+
+def test_device_path_and_errors(engine):
+    import torch
+    from image_restoration_platform_amd.engine import EngineError
+    views = synth.fusion_views(128, 128)
+    out, sh = engine.fuse_tensor(torch.from_numpy(views).cuda(), noise_score=0.3)
+    torch.cuda.synchronize()
+    ref, rsh = ofu.fuse(views, 0.3)
+    assert np.array_equal(out.cpu().numpy(), ref) and np.array_equal(sh.cpu().numpy(), rsh)
+    with pytest.raises(EngineError):
+        engine.fuse(views[:1], 0.1)                                  # k = 1
+    with pytest.raises(EngineError):
+        engine.fuse(np.zeros((2, 40, 64, 3), np.uint8), 0.1)        # too small
+
+
+def test_fusion_full_size(engine):
+    """BASELINE cfg3 shape (3 x 1024^2): the oracle finishes in seconds (vectorised numpy)."""
+    views = synth.fusion_views(1024, 1024)
+    out, sh = engine.fuse(views, noise_score=0.25)
+    ref, rsh = ofu.fuse(views, 0.25)
+    assert np.array_equal(sh, rsh) and np.array_equal(out, ref)
