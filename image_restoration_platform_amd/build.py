@@ -72,9 +72,26 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    build_node_addon()
     if verbose:
         print("built", LIB)
     return LIB
+
+
+def build_node_addon():
+    """N-API shim for the server-node worker (plain g++; N-API symbols resolve from the node binary)."""
+    src = os.path.join(HERE, "node", "ire_napi.cc")
+    out = os.path.join(HERE, "node", "ire_napi.node")
+    inc = "/usr/include/node"
+    if not os.path.exists(os.path.join(inc, "node_api.h")):
+        return None   # no node headers on this host: the Python/ctypes host is unaffected
+    if os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(src), _deps_mtime()):
+        return out
+    r = subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-I" + inc, "-DNODE_GYP_MODULE_NAME=ire_napi", src, "-o", out, "-ldl"],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("node addon build failed:\n" + r.stderr[-2000:])
+    return out
 
 
 if __name__ == "__main__":

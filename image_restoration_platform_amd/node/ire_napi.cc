@@ -1,0 +1,204 @@
+// ire_napi.cc -- thin N-API shim over the C ABI of libire.so (include/ire.h) for the server-node worker.
+//
+// BASELINE.json's north_star names node-ffi-napi; that module is not installable offline, so
+// this shim is the guaranteed path (N-API v8 headers ship with node: /usr/include/node/node_api.h) and
+// node/ire_ffi.mjs keeps the equivalent ffi-napi declaration.  Every engine call runs as napi async work
+// on the libuv pool and resolves a Promise, because the reference's seams are asynchronous
+// (classifier.analyze / geminiClient.restoreImage are awaited: restorator.js:59-94) and must tolerate >= 8
+// calls in flight.  libire.so is dlopen'ed at run time so the addon builds and loads on GPU-less hosts;
+// without a device ire_init fails and the rejection text contains "service unavailable".
+//
+// Build: g++ -O2 -shared -fPIC -I/usr/include/node ire_napi.cc -o ire_napi.node -ldl
+#include <dlfcn.h>
+#include <node_api.h>
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ire.h"
+
+namespace {
+
+struct Api {
+    void* so = nullptr;
+    decltype(&ire_init) init = nullptr;
+    decltype(&ire_shutdown) shutdown = nullptr;
+    decltype(&ire_last_error) last_error = nullptr;
+    decltype(&ire_classify) classify = nullptr;
+    decltype(&ire_restore) restore = nullptr;
+    decltype(&ire_fuse) fuse = nullptr;
+    decltype(&ire_abi_version) abi_version = nullptr;
+} g;
+
+bool load_api(const char* path, std::string* err) {
+    if (g.so) return true;
+    g.so = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!g.so) { *err = std::string("service unavailable: cannot load ") + path + ": " + dlerror(); return false; }
+#define SYM(field, name) g.field = (decltype(g.field))dlsym(g.so, name); if (!g.field) { *err = "service unavailable: missing symbol " name; return false; }
+    SYM(init, "ire_init") SYM(shutdown, "ire_shutdown") SYM(last_error, "ire_last_error") SYM(classify, "ire_classify")
+    SYM(restore, "ire_restore") SYM(fuse, "ire_fuse") SYM(abi_version, "ire_abi_version")
+#undef SYM
+    return true;
+}
+
+void throw_err(napi_env env, const std::string& m) { napi_throw_error(env, nullptr, m.c_str()); }
+
+int64_t get_i64(napi_env env, napi_value v) { int64_t x = 0; napi_get_value_int64(env, v, &x); return x; }
+double get_f64(napi_env env, napi_value v) { double x = 0; napi_get_value_double(env, v, &x); return x; }
+
+// ---- async job -------------------------------------------------------------------------------------
+struct Job {
+    enum Kind { CLASSIFY, RESTORE, FUSE } kind;
+    ire_engine* eng;
+    std::vector<uint8_t> in, jpeg, out;
+    int n, h, w;
+    double noise;
+    std::vector<double> scores;
+    std::vector<int32_t> labels;
+    ire_timings t{};
+    int status = 0;
+    std::string err;
+    napi_deferred deferred;
+    napi_async_work work;
+};
+
+void execute(napi_env, void* data) {
+    Job* j = (Job*)data;
+    switch (j->kind) {
+        case Job::CLASSIFY:
+            j->scores.resize(7 * (size_t)j->n); j->labels.resize(j->n);
+            j->status = g.classify(j->eng, j->in.data(), j->n, j->h, j->w, 3 * j->w, j->jpeg.data(), j->scores.data(), j->labels.data());
+            break;
+        case Job::RESTORE:
+            j->out.resize(j->in.size());
+            j->status = g.restore(j->eng, j->in.data(), j->n, j->h, j->w, nullptr, j->jpeg.data(), j->out.data(), &j->t);
+            break;
+        case Job::FUSE:
+            j->out.resize((size_t)j->h * j->w * 3); j->labels.resize(2 * j->n);
+            j->status = g.fuse(j->eng, j->in.data(), j->n, j->h, j->w, j->noise, j->out.data(), j->labels.data(), &j->t);
+            break;
+    }
+    if (j->status != 0) j->err = g.last_error();   // thread-local: read on the worker thread
+}
+
+void complete(napi_env env, napi_status, void* data) {
+    Job* j = (Job*)data;
+    if (j->status != 0) {
+        napi_value msg, err, code;
+        napi_create_string_utf8(env, j->err.c_str(), NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, nullptr, msg, &err);
+        const char* codes[] = {"", "ENGINE_INVALID_INPUT", "ENGINE_TIMEOUT", "ENGINE_UNAVAILABLE", "ENGINE_INTERNAL"};
+        napi_create_string_utf8(env, codes[j->status >= 1 && j->status <= 4 ? j->status : 4], NAPI_AUTO_LENGTH, &code);
+        napi_set_named_property(env, err, "code", code);     // restorator.js:159 propagates error.code
+        napi_reject_deferred(env, j->deferred, err);
+    } else {
+        napi_value res;
+        napi_create_object(env, &res);
+        if (j->kind == Job::CLASSIFY) {
+            napi_value ab, ta; void* p;
+            napi_create_arraybuffer(env, j->scores.size() * 8, &p, &ab); std::memcpy(p, j->scores.data(), j->scores.size() * 8);
+            napi_create_typedarray(env, napi_float64_array, j->scores.size(), ab, 0, &ta);
+            napi_set_named_property(env, res, "scores", ta);
+            napi_create_arraybuffer(env, j->labels.size() * 4, &p, &ab); std::memcpy(p, j->labels.data(), j->labels.size() * 4);
+            napi_create_typedarray(env, napi_int32_array, j->labels.size(), ab, 0, &ta);
+            napi_set_named_property(env, res, "labels", ta);
+        } else {
+            napi_value buf; void* p;
+            napi_create_buffer_copy(env, j->out.size(), j->out.data(), &p, &buf);
+            napi_set_named_property(env, res, "pixels", buf);
+            napi_value ms; napi_create_double(env, j->t.restore_ms, &ms); napi_set_named_property(env, res, "restore_ms", ms);
+            napi_create_double(env, j->t.classify_ms, &ms); napi_set_named_property(env, res, "classify_ms", ms);
+            if (j->kind == Job::FUSE) {
+                napi_value ab, ta;
+                napi_create_arraybuffer(env, j->labels.size() * 4, &p, &ab); std::memcpy(p, j->labels.data(), j->labels.size() * 4);
+                napi_create_typedarray(env, napi_int32_array, j->labels.size(), ab, 0, &ta);
+                napi_set_named_property(env, res, "shifts", ta);
+            }
+        }
+        napi_resolve_deferred(env, j->deferred, res);
+    }
+    napi_delete_async_work(env, j->work);
+    delete j;
+}
+
+// submit(kind, engineHandle(external), pixels Buffer, n, h, w, jpegFlags Buffer|null, noise) -> Promise
+napi_value submit(napi_env env, napi_callback_info info, Job::Kind kind) {
+    size_t argc = 7; napi_value argv[7];
+    napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+    if (argc < 5) { throw_err(env, "invalid arguments"); return nullptr; }
+    void* eng = nullptr;
+    if (napi_get_value_external(env, argv[0], &eng) != napi_ok || !eng) { throw_err(env, "invalid engine handle"); return nullptr; }
+    void* data; size_t len;
+    if (napi_get_buffer_info(env, argv[1], &data, &len) != napi_ok) { throw_err(env, "invalid input: pixels must be a Buffer"); return nullptr; }
+    Job* j = new Job();
+    j->kind = kind; j->eng = (ire_engine*)eng;
+    j->n = (int)get_i64(env, argv[2]); j->h = (int)get_i64(env, argv[3]); j->w = (int)get_i64(env, argv[4]);
+    const size_t need = (size_t)(j->n > 0 ? j->n : 0) * (j->h > 0 ? j->h : 0) * (j->w > 0 ? j->w : 0) * 3;
+    napi_value promise;
+    napi_create_promise(env, &j->deferred, &promise);
+    if (need == 0 || len < need) {
+        napi_value msg, err;
+        napi_create_string_utf8(env, "invalid input: pixel buffer smaller than n*h*w*3", NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, nullptr, msg, &err);
+        napi_reject_deferred(env, j->deferred, err);
+        delete j;
+        return promise;
+    }
+    j->in.assign((uint8_t*)data, (uint8_t*)data + need);       // the caller's Buffer is not retained
+    j->jpeg.assign(j->n, 1);
+    if (argc > 5) {
+        void* jd; size_t jl;
+        if (napi_get_buffer_info(env, argv[5], &jd, &jl) == napi_ok && jl >= (size_t)j->n) std::memcpy(j->jpeg.data(), jd, j->n);
+    }
+    j->noise = argc > 6 ? get_f64(env, argv[6]) : -1.0;
+    napi_value name;
+    napi_create_string_utf8(env, "ire", NAPI_AUTO_LENGTH, &name);
+    napi_create_async_work(env, nullptr, name, execute, complete, j, &j->work);
+    napi_queue_async_work(env, j->work);
+    return promise;
+}
+napi_value classify_async(napi_env e, napi_callback_info i) { return submit(e, i, Job::CLASSIFY); }
+napi_value restore_async(napi_env e, napi_callback_info i) { return submit(e, i, Job::RESTORE); }
+napi_value fuse_async(napi_env e, napi_callback_info i) { return submit(e, i, Job::FUSE); }
+
+void finalize_engine(napi_env, void* data, void*) { if (data && g.shutdown) g.shutdown((ire_engine*)data); }
+
+// init(libPath, weightsPath|null, deviceIndex, maxBatch, numStreams) -> engine handle (throws with the engine's message)
+napi_value init_engine(napi_env env, napi_callback_info info) {
+    size_t argc = 5; napi_value argv[5];
+    napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+    char lib[1024] = {0}, wts[1024] = {0}; size_t l = 0;
+    if (argc < 1 || napi_get_value_string_utf8(env, argv[0], lib, sizeof(lib), &l) != napi_ok) { throw_err(env, "invalid arguments"); return nullptr; }
+    bool have_w = argc > 1 && napi_get_value_string_utf8(env, argv[1], wts, sizeof(wts), &l) == napi_ok && l > 0;
+    std::string err;
+    if (!load_api(lib, &err)) { throw_err(env, err); return nullptr; }
+    ire_config cfg; std::memset(&cfg, 0, sizeof(cfg));
+    cfg.struct_size = sizeof(cfg);
+    cfg.device_index = argc > 2 ? (int)get_i64(env, argv[2]) : 0;
+    cfg.max_batch = argc > 3 ? (int)get_i64(env, argv[3]) : 8;
+    cfg.num_streams = argc > 4 ? (int)get_i64(env, argv[4]) : 0;
+    cfg.weights_path = have_w ? wts : nullptr;
+    ire_engine* e = nullptr;
+    const int rc = g.init(&cfg, &e);
+    if (rc != 0) { throw_err(env, g.last_error()); return nullptr; }
+    napi_value ext;
+    napi_create_external(env, e, finalize_engine, nullptr, &ext);
+    return ext;
+}
+
+napi_value module_init(napi_env env, napi_value exports) {
+    napi_property_descriptor d[] = {
+        {"init", nullptr, init_engine, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"classifyAsync", nullptr, classify_async, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"restoreAsync", nullptr, restore_async, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"fuseAsync", nullptr, fuse_async, nullptr, nullptr, nullptr, napi_default, nullptr},
+    };
+    napi_define_properties(env, exports, 4, d);
+    return exports;
+}
+
+}  // namespace
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, module_init)

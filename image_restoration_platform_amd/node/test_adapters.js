@@ -1,0 +1,66 @@
+// Contract test of the two seams (mirrors server-node/tests/restoratorService.test.js:18-79 for the
+// engine-backed objects).  Usage: node test_adapters.js <case.json>; prints one JSON line.
+// The codec is a raw one ("RAW1" + u16 width + u16 height + u8 isJpeg + RGB) because sharp is not installable here.
+'use strict';
+const fs = require('fs');
+const ad = require('./engine_adapters.js');
+
+const rawCodec = {
+  decode: async (buf) => {
+    if (buf.length < 9 || buf.toString('ascii', 0, 4) !== 'RAW1') throw new Error('Input buffer contains unsupported image format');
+    const w = buf.readUInt16LE(4), h = buf.readUInt16LE(6);
+    return { data: buf.slice(9, 9 + w * h * 3), width: w, height: h, format: buf[8] ? 'jpeg' : 'png' };
+  },
+  encode: async (o) => Buffer.concat([Buffer.from('RAW1'), Buffer.from([o.width & 255, o.width >> 8, o.height & 255, o.height >> 8, 0]), o.data]),
+};
+
+// minimal RestoratorService-shaped harness (restorator.js:37-172 contract: never throws, envelope fields)
+async function restoreLikeReference(classifier, restorer, imageBuffer) {
+  const timings = {};
+  const t0 = Date.now();
+  try {
+    let t = Date.now();
+    const degradation = await classifier.analyze(imageBuffer);
+    timings.classify_ms = Date.now() - t;
+    t = Date.now();
+    const r = await restorer.restoreImage({ prompt: 'p', images: [imageBuffer], userContext: { userId: 'u' } });
+    timings.restore_ms = Date.now() - t;
+    return { success: true, degradationAnalysis: degradation, restoredImage: r.base64Image, metadata: r.metadata, timings };
+  } catch (error) {
+    return { success: false, error: { message: error.message, code: error.code || 'RESTORATION_FAILED' }, timings, total: Date.now() - t0 };
+  }
+}
+
+(async () => {
+  const spec = JSON.parse(fs.readFileSync(process.argv[2], 'utf8'));
+  const out = { loaded: true };
+  let engine;
+  try {
+    engine = ad.createEngine({ weightsPath: spec.weights, maxBatch: 8 });
+    out.engine = true;
+  } catch (e) {
+    out.engine = false;
+    out.initError = e.message;
+    console.log(JSON.stringify(out));
+    return;
+  }
+  const classifier = ad.createEngineClassifier({ engine, codec: rawCodec });
+  const restorer = ad.createEngineRestorer({ engine, codec: rawCodec });
+  const img = fs.readFileSync(spec.image);
+  // >= 8 calls in flight (the reference keeps 3 per batch / 5 per worker in flight)
+  const many = await Promise.all(Array.from({ length: 8 }, () => classifier.analyze(img)));
+  out.scores = many[0];
+  out.allEqual = many.every((m) => JSON.stringify(m) === JSON.stringify(many[0]));
+  const r = await restoreLikeReference(classifier, restorer, img);
+  out.success = r.success;
+  out.metadata = r.metadata;
+  out.restoredSha = require('crypto').createHash('sha256').update(Buffer.from(r.restoredImage, 'base64').slice(9)).digest('hex');
+  const bad = await restoreLikeReference(classifier, restorer, Buffer.from('not an image'));
+  out.bad = bad;
+  if (spec.fuse) {
+    const views = spec.fuse.map((f) => fs.readFileSync(f));
+    const fr = await restorer.restoreImage({ prompt: 'p', images: views });
+    out.fusedLen = Buffer.from(fr.base64Image, 'base64').length;
+  }
+  console.log(JSON.stringify(out));
+})().catch((e) => { console.log(JSON.stringify({ fatal: e.message })); process.exit(1); });

@@ -1,0 +1,46 @@
+"""server-python path: FastAPI app over the engine (extends the reference's /health stub, main.py:1-7)."""
+import base64
+import io
+
+import numpy as np
+import pytest
+from fastapi.testclient import TestClient
+
+from image_restoration_platform_amd import synth
+from image_restoration_platform_amd.serving import app as appmod
+
+
+def _jpeg(img):
+    from PIL import Image
+    b = io.BytesIO()
+    Image.fromarray(img).save(b, format="JPEG", quality=85, subsampling=0)
+    return b.getvalue()
+
+
+def test_health_matches_reference_stub_and_no_fallback():
+    import torch
+    c = TestClient(appmod.app)
+    assert c.get("/health").json() == {"ok": True, "service": "python"}      # server-python/main.py:5-7
+    assert c.post("/restore", content=b"").status_code == 400
+    if not torch.cuda.is_available():
+        r = c.post("/restore", content=_jpeg(synth.image(0, 64, 64)))
+        assert r.status_code == 503 and "service unavailable" in r.json()["detail"]
+        assert c.get("/health/ready").status_code == 503
+
+
+@pytest.mark.gpu
+def test_restore_and_fuse_endpoints():
+    from PIL import Image
+    c = TestClient(appmod.app)
+    r = c.post("/restore?prompt=fix", content=_jpeg(synth.image(2, 96, 120)))
+    assert r.status_code == 200, r.text
+    j = r.json()
+    assert j["success"] and "User request: fix." in j["enhancedPrompt"]
+    out = np.asarray(Image.open(io.BytesIO(base64.b64decode(j["restoredImage"]))))
+    assert out.shape == (96, 120, 3)
+    assert c.post("/restore", content=b"garbage").status_code == 400
+    views = synth.fusion_views(64, 64)
+    r = c.post("/fuse", json={"images": [base64.b64encode(_jpeg(v)).decode() for v in views]})
+    assert r.status_code == 200 and r.json()["metadata"]["estimatedCostUsd"] == 0
+    assert c.post("/fuse", json={"images": ["AAAA"]}).status_code == 400
+    assert c.get("/health/ready").json()["ok"] is True
