@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("IRE_STREAMS", "0")))
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("IRE_STREAMS", "2")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the in-engine HIP-event kernel timing")
     args = ap.parse_args()
@@ -126,11 +126,20 @@ def main():
         }
         if prof is not None:
             c3 = prof["conv3x3"]
+            # HBM bytes per launch from PMC counters cannot be collected from inside this process; they come from the
+            # committed rocprofv3 --pmc passes of this same command (profiles/r01_traffic.json, FETCH_SIZE doubled per
+            # MI355X_MICROARCH.md), valid for the default 1024x1024 bs=8 workload only.
+            traffic, traffic_src = None, None
+            tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            if os.path.exists(tj) and S == 1024 and B == 8:
+                with open(tj) as f:
+                    tr = json.load(f)
+                traffic, traffic_src = tr["hbm_bytes_per_launch"], "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
             ach = c3["flops"] / (c3["ms"] * 1e-3) / 1e12 if c3["ms"] > 0 else 0.0
             res["roofline"] = {
                 "kernel": "conv_mfma_kernel (all 3x3 C->C / down / up instantiations)", "bound": "mfma",
                 "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
-                "traffic": None, "launches": c3["launches"], "avg_launch_us": 1e3 * c3["ms"] / max(1, c3["launches"]),
+                "traffic": traffic, "traffic_source": traffic_src, "launches": c3["launches"], "avg_launch_us": 1e3 * c3["ms"] / max(1, c3["launches"]),
                 "algorithmic_gflop_per_launch": c3["flops"] / max(1, c3["launches"]) / 1e9,
                 "hbm_algorithmic_GBs": c3["bytes"] / (c3["ms"] * 1e-3) / 1e9 if c3["ms"] > 0 else 0.0,
                 "family_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},

@@ -412,7 +412,7 @@ void Engine::launch_conv(Lane& L, const ConvW& cw, const void* in0, const void* 
     a.cout = (cw.kind == CONV_HEAD) ? 32 : cw.cout;
     a.tiles_x = ceil_div(Wout, 32);
     const bool rb = (cw.kind == CONV_RB1 || cw.kind == CONV_RB2);
-    const bool up_rb = (cw.kind == CONV_UP) && rb_tile_h_ == kRbTileH;
+    const bool up_rb = (cw.kind == CONV_UP) && rb_tile_h_ == kRbTileH && cw.cout >= 64;   // 64->32 @full res: v1 is faster (measured)
     a.tiles_y = ceil_div(Hout, (rb || up_rb) ? rb_tile_h_ : conv_tile_h(cw.kind));
     if (up_rb) a.stats = nullptr;
     a.nimg = nimg; a.nblocks = cw.nblocks;

@@ -131,7 +131,11 @@ napi_value submit(napi_env env, napi_callback_info info, Job::Kind kind) {
     void* eng = nullptr;
     if (napi_get_value_external(env, argv[0], &eng) != napi_ok || !eng) { throw_err(env, "invalid engine handle"); return nullptr; }
     void* data; size_t len;
-    if (napi_get_buffer_info(env, argv[1], &data, &len) != napi_ok) { throw_err(env, "invalid input: pixels must be a Buffer"); return nullptr; }
+    bool is_buf = false;   // napi_get_buffer_info aborts the process on non-buffers in Node 12: test first
+    if (napi_is_buffer(env, argv[1], &is_buf) != napi_ok || !is_buf || napi_get_buffer_info(env, argv[1], &data, &len) != napi_ok) {
+        throw_err(env, "invalid input: pixels must be a Buffer");
+        return nullptr;
+    }
     Job* j = new Job();
     j->kind = kind; j->eng = (ire_engine*)eng;
     j->n = (int)get_i64(env, argv[2]); j->h = (int)get_i64(env, argv[3]); j->w = (int)get_i64(env, argv[4]);
@@ -150,7 +154,10 @@ napi_value submit(napi_env env, napi_callback_info info, Job::Kind kind) {
     j->jpeg.assign(j->n, 1);
     if (argc > 5) {
         void* jd; size_t jl;
-        if (napi_get_buffer_info(env, argv[5], &jd, &jl) == napi_ok && jl >= (size_t)j->n) std::memcpy(j->jpeg.data(), jd, j->n);
+        bool jb = false;
+        if (napi_is_buffer(env, argv[5], &jb) == napi_ok && jb && napi_get_buffer_info(env, argv[5], &jd, &jl) == napi_ok &&
+            jl >= (size_t)j->n)
+            std::memcpy(j->jpeg.data(), jd, j->n);
     }
     j->noise = argc > 6 ? get_f64(env, argv[6]) : -1.0;
     napi_value name;
