@@ -17,7 +17,8 @@ LIB = os.path.join(HERE, "lib", "libire.so")
 SOURCES = [
     ("classifier.hip", ["-ffp-contract=off"]),
     ("conv_mfma.hip", []),
-    ("conv_rb.hip", ["-DIRE_RB_ABLATE"] if os.environ.get("IRE_RB_ABLATE") else []),
+    ("conv_rb.hip", (["-DIRE_RB_ABLATE"] if os.environ.get("IRE_RB_ABLATE") else []) +
+     (["-DIRE_RB_DEFER=" + os.environ["IRE_RB_DEFER"]] if os.environ.get("IRE_RB_DEFER") else [])),
     ("gn.hip", []),
     ("fusion.hip", []),
     ("engine.cpp", []),

@@ -34,6 +34,8 @@ struct ConvArgs {
     int Hin, Win, Hout, Wout, cout;
     int tiles_x, tiles_y, nimg, nblocks;
     int group_size;              // cout / 8
+    int prio_young;              // conv_rb: raise the issue priority of waves 4-7
+    unsigned long long* stamps;  // diagnostic builds only (IRE_RB_ABLATE, DBG bit 16): s_memtime stamps, else null
 };
 
 int conv_tile_h(ConvKind kind);       // output rows per workgroup tile (columns: 32)

@@ -75,7 +75,15 @@ struct RbCfg {
     // streaming: [in0 | w0][in1 | w1]; resident weights: [in0][in1][w]
     static constexpr int BUF_STRIDE = WRES ? RB_IN_BYTES : RB_IN_BYTES + W_BYTES;
     static constexpr int W_OFF0 = WRES ? 2 * RB_IN_BYTES : RB_IN_BYTES;
-    static constexpr int MAIN_BYTES = WRES ? 2 * RB_IN_BYTES + W_BYTES : 2 * (RB_IN_BYTES + W_BYTES);
+    // WRES (C = 32): [in0][in1][w][O]; O = 32 KB parking space of the previous item's output tile, drained
+    // (residual add, statistics, stores) inside the NEXT stage's MFMA loop ("deferred epilogue").
+#ifndef IRE_RB_DEFER
+#define IRE_RB_DEFER 1
+#endif
+    static constexpr bool DEFER = WRES && (IRE_RB_DEFER != 0);
+    static constexpr int OUT_TILE_BYTES = RB_TH * RB_TW * NT * 2;
+    static constexpr int O_OFF = 2 * RB_IN_BYTES + W_BYTES;
+    static constexpr int MAIN_BYTES = WRES ? 2 * RB_IN_BYTES + W_BYTES + OUT_TILE_BYTES : 2 * (RB_IN_BYTES + W_BYTES);
     static constexpr int RED_BYTES = 8 * (NT / 8) * 4 * 4;
     static constexpr int COEF_BYTES = 2 * 256;              // two stages x 32 channels x (A,B) floats
     static constexpr int BIAS_BYTES = 256 * 4;              // the layer's whole bias vector (cout <= 256)
@@ -99,6 +107,14 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int c8_fixed = tid & 3;  // this thread always stages the same 8-channel slice of a pixel
+    // diagnostic stamps (DBG & 16): lane 0 of waves 0 and 4 of the first 8 workgroups, 6 stamps x 64 stages
+    auto stamp = [&](int s, int k) {
+        if constexpr (DBG & 16) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (a.stamps && lane == 0 && (wave == 0 || wave == 4) && blockIdx.x < 8 && s < 64)
+                a.stamps[(((size_t)blockIdx.x * 2 + (wave >> 2)) * 64 + s) * 6 + k] = t;
+        }
+    };
 
     // ---- persistent work assignment (XCD-aware: blocks b and b+8 share an XCD / L2) ----------------
     const int tiles_per_img = a.tiles_x * a.tiles_y;
@@ -271,6 +287,101 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         st_img = -1;
     };
 
+    // ---- epilogue building blocks ------------------------------------------------------------------------
+    struct DrainStats { float sA, qA, sB, qB; };
+    // out tile [512 px][NT] bf16; 16-B chunk cc of pixel p lives at chunk cc ^ (p & (NCC-1)).  Accumulator i of lane
+    // (r = pixel column, h) is cout j*32 + 8*(i>>2) + 4h + (i&3): 4 consecutive couts -> one 8-byte LDS write.
+    auto acc_to_lds = [&](const RbItem& it, unsigned char* lds_ob) {
+        const int cout0 = it.nb * NT;
+        int r_e = r, h_e = h;
+        asm volatile("" : "+v"(r_e), "+v"(h_e));   // index math recomputed here (hoisted copies were spilled)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bv = *reinterpret_cast<const float4*>(
+                    reinterpret_cast<const float*>(smem + C::MAIN_BYTES + C::RED_BYTES + C::COEF_BYTES) + cout0 + j * 32 + 8 * q + 4 * h_e);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int pix = (wave * 2 + m) * RB_TW + r_e;
+                    const int cc = j * 4 + q;                     // 16-B chunk holding couts 8q..8q+7 of n-tile j
+                    uint2 v;
+                    v.x = rb_pack(acc[m][j][4 * q + 0] + bv.x, acc[m][j][4 * q + 1] + bv.y);
+                    v.y = rb_pack(acc[m][j][4 * q + 2] + bv.z, acc[m][j][4 * q + 3] + bv.w);
+                    *reinterpret_cast<uint2*>(lds_ob + (pix * NCC + (cc ^ (pix & (NCC - 1)))) * 16 + h_e * 8) = v;
+                }
+            }
+        }
+        // the accumulators are dead until the next item zeroes them: tell the register allocator
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) asm volatile("" : "=v"(acc[m][j]));
+    };
+    // residual tile: all loads issued together, addresses clamped into the image (stores are predicated)
+    auto drain_load_resid = [&](const RbItem& it, uint4 (&rv)[C::OUT_ITERS]) {
+        if constexpr (RESID && !(DBG & 4)) {
+            int te = tid;
+            asm volatile("" : "+v"(te));
+            const int cc = te % NCC;
+            const int oy0 = it.ty * RB_TH, ox0 = it.tx * RB_TW, cout0 = it.nb * NT;
+#pragma unroll
+            for (int k = 0; k < C::OUT_ITERS; ++k) {
+                const int pix = (te + k * RB_THREADS) / NCC;
+                const int oy = min(oy0 + (pix >> 5), a.Hout - 1), ox = min(ox0 + (pix & 31), a.Wout - 1);
+                const size_t g = (((size_t)it.img * a.Hout + oy) * a.Wout + ox) * a.cout + cout0 + cc * 8;
+                rv[k] = *reinterpret_cast<const uint4*>(a.resid + g);
+            }
+        }
+    };
+    // one 16-B chunk of the parked tile: + residual, GroupNorm partial sums, full-line store.  Branch-free except
+    // the store predicate (valid = false on the first stage, when nothing is parked yet).
+    auto drain_chunk = [&](int k, const RbItem& it, bool valid, const unsigned char* lds_ob, const uint4 (&rv)[C::OUT_ITERS],
+                           DrainStats& ds) {
+        int te = tid;
+        asm volatile("" : "+v"(te));
+        const int cc = te % NCC;
+        const int oy0 = it.ty * RB_TH, ox0 = it.tx * RB_TW, cout0 = it.nb * NT;
+        const int idx = te + k * RB_THREADS;
+        const int pix = idx / NCC;
+        const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
+        const bool inb = valid && oy < a.Hout && ox < a.Wout;
+        const uint4 o = reinterpret_cast<const uint4*>(lds_ob)[pix * NCC + (cc ^ (pix & (NCC - 1)))];
+        const size_t g = (((size_t)it.img * a.Hout + oy) * a.Wout + ox) * a.cout + cout0 + cc * 8;
+        unsigned w[4] = {o.x, o.y, o.z, o.w};
+        if constexpr (RESID && !(DBG & 4)) {
+            const unsigned rw[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                w[d] = rb_pack(rb_lo(w[d]) + rb_lo(rw[d]), rb_hi(w[d]) + rb_hi(rw[d]));
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {                      // out-of-image pixels do not count in the statistics
+            const float f0 = inb ? rb_lo(w[d]) : 0.f, f1 = inb ? rb_hi(w[d]) : 0.f;
+            if (d < 2) { ds.sA += f0 + f1; ds.qA += f0 * f0 + f1 * f1; }
+            else { ds.sB += f0 + f1; ds.qB += f0 * f0 + f1 * f1; }
+        }
+        if (inb) {
+            if constexpr (DBG & 4) { if (w[0] == 0x12345678u) a.out[g] = 1; }
+            else *reinterpret_cast<uint4*>(a.out + g) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    };
+    auto drain_finish = [&](const RbItem& it, bool valid, DrainStats& ds) {
+        if (!valid) return;                                    // wave-uniform
+#pragma unroll
+        for (int off = NCC; off < 64; off <<= 1) {
+            ds.sA += __shfl_xor(ds.sA, off, 64); ds.qA += __shfl_xor(ds.qA, off, 64);
+            ds.sB += __shfl_xor(ds.sB, off, 64); ds.qB += __shfl_xor(ds.qB, off, 64);
+        }
+        if (lane < NCC) {
+            float* d = red + (wave * NCC + lane) * 4;
+            d[0] = ds.sA; d[1] = ds.qA; d[2] = ds.sB; d[3] = ds.qB;
+        }
+        st_img = it.img; st_tile = it.tile; st_nb = it.nb;
+    };
+    RbItem pend{0, 0, 0, 0, 0};      // deferred epilogue: the item parked in O
+    bool pend_valid = false;
+
     // ---- one pipeline stage (PAR = s & 1 selects buffers and register sets statically) ---------------
     RbRegs R0, R1;
     auto stage = [&](int s, auto par_tag) {
@@ -286,6 +397,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
 
         // (1) coefficients of stage s+1 first, then (3) the input prefetch of stage s+2, so that waiting
         // for (1) never waits for (3) (VMEM returns in issue order)
+        stamp(s, 0);
         // Rn was retired at the end of the previous stage (or of the prologue); say so on every path into the
         // stage, so no wait on it is placed after the weight DMA below (where it would be a vmcnt(0)).
 #pragma unroll
@@ -294,6 +406,9 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         load_coeffs(s & 1, cA, cB);                 // coefficients of stage s+1's data (slot written last stage)
         float4 cnext = fetch_coeffs(s2);            // for the data of stage s+2, transformed during stage s+1
         load_stage(s2, Rf);
+        uint4 drv[C::OUT_ITERS];                    // deferred epilogue: residual of the parked item
+        DrainStats dst{0.f, 0.f, 0.f, 0.f};
+        if constexpr (C::DEFER) drain_load_resid(pend, drv);
 
         if (s - (s / nkc) * nkc == 0) zero_acc();   // new item (not in the epilogue: 64 dead registers there)
         // (4) 18 MFMA k-steps from the current buffer, the s+1 transform interleaved between groups
@@ -336,6 +451,10 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
                 tw[st & 3] = transform_word(word_of(Rn.v[st >> 2], st & 3), st & 3, cA, cB);
                 if ((st & 3) == 3) store_words(st >> 2, Rn, tw, in_nxt);
             }
+            if constexpr (C::DEFER) {
+                if (st >= 10 && ((st - 10) & 1) == 0 && (st - 10) / 2 < C::OUT_ITERS)
+                    drain_chunk((st - 10) / 2, pend, pend_valid, smem + C::O_OFF, drv, dst);
+            }
             if constexpr (!WRES) {
                 // (2) weight slab of stage s+1 by LDS-DMA (global_load_lds_dwordx4: 16 B per lane, no registers), a
                 // pure copy into the OTHER buffer, 17 k-steps ahead of the end-of-stage wait + barrier that publish
@@ -355,6 +474,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        stamp(s, 1);
         tw[2] = transform_word(word_of(Rn.v[4], 2), 2, cA, cB);   // pieces 18, 19: the (partial) fifth chunk
         tw[3] = transform_word(word_of(Rn.v[4], 3), 3, cA, cB);
         store_words(4, Rn, tw, in_nxt);
@@ -367,99 +487,38 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         put_coeffs((s + 1) & 1, cnext);
         // (5) the DMA'd weight slab must have landed before the stage barrier publishes it
         if constexpr (!WRES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // (6) last k-chunk of the item: epilogue through the current buffer
+        stamp(s, 2);
+        // (6) last k-chunk of the item: epilogue
         const int kc = s - (s / nkc) * nkc;
-        if (kc == nkc - 1) {
+        if constexpr (C::DEFER) {
+            // every stage ends an item (nkc == 1).  The previous item's tile was drained inside the loop above;
+            // park this item's tile in O for the next stage.
+            drain_finish(pend, pend_valid, dst);
+            __syncthreads();                                   // all drains of O and all reads of buf[cur] are done
+            stamp(s, 3);
+            flush_stats();
+            const RbItem it = item_of(s);
+            acc_to_lds(it, smem + C::O_OFF);
+            pend = it; pend_valid = true;
+        } else if (kc == nkc - 1) {
             const RbItem it = item_of(s / nkc);
-            const int oy0 = it.ty * RB_TH, ox0 = it.tx * RB_TW;
-            const int cout0 = it.nb * NT;
-            __syncthreads();                                   // every wave is done reading buf[cur]
-            flush_stats();                                     // (red[] of the previous item is complete)
-            // out tile [512 px][NT] bf16 in buf[cur]; 16-B chunk cc of pixel p lives at chunk cc ^ (p & (NCC-1)).
-            // accumulator i of lane (r = pixel column, h) is cout j*32 + 8*(i>>2) + 4h + (i&3): 4 consecutive
-            // couts -> one 8-byte LDS write.
-            unsigned char* lds_ob = smem + PAR * C::BUF_STRIDE;
-            int r_e = r, h_e = h;
-            asm volatile("" : "+v"(r_e), "+v"(h_e));
-#pragma unroll
-            for (int j = 0; j < NTL; ++j) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 bv = *reinterpret_cast<const float4*>(
-                        reinterpret_cast<const float*>(smem + C::MAIN_BYTES + C::RED_BYTES + C::COEF_BYTES) + cout0 + j * 32 + 8 * q + 4 * h_e);
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        const int pix = (wave * 2 + m) * RB_TW + r_e;
-                        const int cc = j * 4 + q;                     // 16-B chunk holding couts 8q..8q+7 of n-tile j
-                        uint2 v;
-                        v.x = rb_pack(acc[m][j][4 * q + 0] + bv.x, acc[m][j][4 * q + 1] + bv.y);
-                        v.y = rb_pack(acc[m][j][4 * q + 2] + bv.z, acc[m][j][4 * q + 3] + bv.w);
-                        *reinterpret_cast<uint2*>(lds_ob + (pix * NCC + (cc ^ (pix & (NCC - 1)))) * 16 + h_e * 8) = v;
-                    }
-                }
-            }
-            // the accumulators are dead until the next item zeroes them: tell the register allocator
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int j = 0; j < NTL; ++j) asm volatile("" : "=v"(acc[m][j]));
-            int te = tid;
-            asm volatile("" : "+v"(te));   // epilogue index math recomputed here (hoisted copies were spilled to scratch)
-            const int cc = te % NCC;
-            // residual tile: all loads issued together, addresses clamped into the image (stores are predicated)
             uint4 rv[C::OUT_ITERS];
-            if constexpr (RESID && !(DBG & 4)) {
-#pragma unroll
-                for (int k = 0; k < C::OUT_ITERS; ++k) {
-                    const int pix = (te + k * RB_THREADS) / NCC;
-                    const int oy = min(oy0 + (pix >> 5), a.Hout - 1), ox = min(ox0 + (pix & 31), a.Wout - 1);
-                    const size_t g = (((size_t)it.img * a.Hout + oy) * a.Wout + ox) * a.cout + cout0 + cc * 8;
-                    rv[k] = *reinterpret_cast<const uint4*>(a.resid + g);
-                }
-            }
+            drain_load_resid(it, rv);                          // before the barrier: covered by the wait for the slow half
+            __syncthreads();                                   // every wave is done reading buf[cur]
+            stamp(s, 3);
+            flush_stats();                                     // (red[] of the previous item is complete)
+            unsigned char* lds_ob = smem + PAR * C::BUF_STRIDE;  // out tile in buf[cur]
+            acc_to_lds(it, lds_ob);
             __syncthreads();
-            float sA = 0.f, qA = 0.f, sB = 0.f, qB = 0.f;
-            const uint4* lds_o4 = reinterpret_cast<const uint4*>(lds_ob);
+            DrainStats ds{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < C::OUT_ITERS; ++k) {
-                const int idx = te + k * RB_THREADS;
-                const int pix = idx / NCC;
-                const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
-                const bool inb = oy < a.Hout && ox < a.Wout;
-                const uint4 o = lds_o4[pix * NCC + (cc ^ (pix & (NCC - 1)))];
-                const size_t g = (((size_t)it.img * a.Hout + oy) * a.Wout + ox) * a.cout + cout0 + cc * 8;
-                unsigned w[4] = {o.x, o.y, o.z, o.w};
-                if constexpr (RESID && !(DBG & 4)) {
-                    const unsigned rw[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w};
-#pragma unroll
-                    for (int d = 0; d < 4; ++d)
-                        w[d] = rb_pack(rb_lo(w[d]) + rb_lo(rw[d]), rb_hi(w[d]) + rb_hi(rw[d]));
-                }
-                const float msk = inb ? 1.f : 0.f;           // out-of-image pixels do not count in the statistics
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const float f0 = rb_lo(w[d]) * msk, f1 = rb_hi(w[d]) * msk;
-                    if (d < 2) { sA += f0 + f1; qA += f0 * f0 + f1 * f1; }
-                    else { sB += f0 + f1; qB += f0 * f0 + f1 * f1; }
-                }
-                if (inb) {
-                    if constexpr (DBG & 4) { if (w[0] == 0x12345678u) a.out[g] = 1; }
-                    else *reinterpret_cast<uint4*>(a.out + g) = make_uint4(w[0], w[1], w[2], w[3]);
-                }
-            }
-#pragma unroll
-            for (int off = NCC; off < 64; off <<= 1) {
-                sA += __shfl_xor(sA, off, 64); qA += __shfl_xor(qA, off, 64);
-                sB += __shfl_xor(sB, off, 64); qB += __shfl_xor(qB, off, 64);
-            }
-            if (lane < NCC) {
-                float* d = red + (wave * NCC + lane) * 4;
-                d[0] = sA; d[1] = qA; d[2] = sB; d[3] = qB;
-            }
-            st_img = it.img; st_tile = it.tile; st_nb = it.nb;
+            for (int k = 0; k < C::OUT_ITERS; ++k) drain_chunk(k, it, true, lds_ob, rv, ds);
+            drain_finish(it, true, ds);
         }
+        stamp(s, 4);
         // (7) stage barrier: buf[nxt] complete, buf[cur] (and red[]) free
         __syncthreads();
+        stamp(s, 5);
     };
 
     // ---- prologue: stage 0 into buffer 0, stage 1 into registers --------------------------------------
@@ -488,9 +547,22 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
     }
     __syncthreads();
 
+    // Waves 4-7 are the later-dispatched partners on each SIMD and lose issue arbitration to waves 0-3 on every
+    // stage (measured with s_memtime: their MFMA loop took 6600 vs 4600 cycles, the older half then idles at the
+    // barrier).  One static priority raise, no per-stage flips (cdna guide T5, static form); IRE_RB_PRIO=0 disables.
+    if (a.prio_young && __builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1);
     for (int s = 0; s < S; s += 2) {
         stage(s, std::integral_constant<int, 0>{});
         if (s + 1 < S) stage(s + 1, std::integral_constant<int, 1>{});
+    }
+    if constexpr (C::DEFER) {   // the last item is still parked in O (made visible by the last stage barrier)
+        uint4 drv[C::OUT_ITERS];
+        DrainStats dst{0.f, 0.f, 0.f, 0.f};
+        drain_load_resid(pend, drv);
+#pragma unroll
+        for (int k = 0; k < C::OUT_ITERS; ++k) drain_chunk(k, pend, pend_valid, smem + C::O_OFF, drv, dst);
+        drain_finish(pend, pend_valid, dst);
+        __syncthreads();
     }
     flush_stats();
 }
@@ -535,6 +607,7 @@ void conv_rb_launch(bool resid, bool fused_act, const ConvArgs& a, hipStream_t s
         case 8: return rb_dispatch<8>(resid, fused_act, a, stream);
         case 6: return rb_dispatch<6>(resid, fused_act, a, stream);
         case 14: return rb_dispatch<14>(resid, fused_act, a, stream);
+        case 16: return rb_dispatch<16>(resid, fused_act, a, stream);
         default: break;
     }
 #endif

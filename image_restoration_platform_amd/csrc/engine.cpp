@@ -56,6 +56,11 @@ Engine::Engine(const ire_config& cfg) {
     flags_ = cfg.flags;
     if (const char* v = std::getenv("IRE_CONV_V1")) rb_tile_h_ = (v[0] == '1') ? 8 : kRbTileH;
     if (const char* v = std::getenv("IRE_ACT_SPLIT_MINC")) act_split_min_c_ = std::atoi(v);
+    if (const char* v = std::getenv("IRE_RB_PRIO")) prio_young_ = std::atoi(v);
+    if (const char* v = std::getenv("IRE_RB_STAMPS")) {   // diagnostic: "<cout>[r]" = stamp the first such ResBlock conv
+        stamps_cout_ = std::atoi(v);
+        stamps_resid_ = std::strchr(v, 'r') != nullptr;
+    }
 
     IRE_HIP(hipStreamCreateWithFlags(&main_stream_, hipStreamNonBlocking));
     for (auto& ev : ev_) IRE_HIP(hipEventCreate(&ev));
@@ -75,6 +80,10 @@ Engine::Engine(const ire_config& cfg) {
     IRE_HIP(hipMemcpy(d_thr, kGreyThr, sizeof(kGreyThr), hipMemcpyHostToDevice));
     IRE_HIP(hipMemcpy(d_inv, kGreyInv, sizeof(kGreyInv), hipMemcpyHostToDevice));
     tables_ = ClassifierTables{d_lin, d_thr, d_inv};
+    if (stamps_cout_) {
+        stamps_dev_ = (unsigned long long*)dalloc(8 * 2 * 64 * 6 * 8);
+        IRE_HIP(hipMemset(stamps_dev_, 0, 8 * 2 * 64 * 6 * 8));
+    }
 
     if (cfg.weights_path && cfg.weights_path[0]) load_weights_file(cfg.weights_path);
 }
@@ -82,6 +91,25 @@ Engine::Engine(const ire_config& cfg) {
 Engine::~Engine() {
     (void)hipSetDevice(device_);
     (void)hipDeviceSynchronize();
+    if (stamps_dev_) {   // diagnostic dump: per-stage phase durations (s_memtime ticks = shader clocks / 100 MHz ref? printed raw)
+        std::vector<unsigned long long> h(8 * 2 * 64 * 6);
+        (void)hipMemcpy(h.data(), stamps_dev_, h.size() * 8, hipMemcpyDeviceToHost);
+        const char* names[5] = {"top->mfma_loop_end", "->vmcnt0", "->epi_barrier1", "->epilogue_end", "->stage_barrier"};
+        for (int wg = 0; wg < 2; ++wg)
+            for (int wv = 0; wv < 2; ++wv) {
+                std::fprintf(stderr, "[stamps] wg %d wave %d (ticks per segment; -1 = not taken)\n", wg, wv * 4);
+                for (int s = 0; s < 40; ++s) {
+                    const unsigned long long* t = &h[(((size_t)wg * 2 + wv) * 64 + s) * 6];
+                    if (!t[0]) continue;
+                    long long d01 = (long long)(t[1] - t[0]), d12 = (long long)(t[2] - t[1]);
+                    long long d23 = t[3] ? (long long)(t[3] - t[2]) : -1, d34 = t[3] ? (long long)(t[4] - t[3]) : (long long)(t[4] - t[2]);
+                    long long d45 = (long long)(t[5] - t[4]);
+                    std::fprintf(stderr, "  s%02d %s=%lld %s=%lld %s=%lld %s=%lld %s=%lld | stage=%lld\n", s, names[0], d01, names[1], d12,
+                                 names[2], d23, names[3], d34, names[4], d45, (long long)(t[5] - t[0]));
+                }
+            }
+        (void)hipFree(stamps_dev_);
+    }
     free_workspace();
     for (void* p : net_.allocs) (void)hipFree(p);
     for (void* p : table_allocs_) (void)hipFree(p);
@@ -417,6 +445,12 @@ void Engine::launch_conv(Lane& L, const ConvW& cw, const void* in0, const void* 
     if (up_rb) a.stats = nullptr;
     a.nimg = nimg; a.nblocks = cw.nblocks;
     a.group_size = std::max(1, a.cout / 8);
+    a.stamps = nullptr;
+    a.prio_young = prio_young_;
+    if (stamps_dev_ && rb && cw.cout == stamps_cout_ && (cw.kind == CONV_RB2) == stamps_resid_ && !stamps_taken_) {
+        a.stamps = stamps_dev_;
+        stamps_taken_ = true;
+    }
     const int taps = (cw.kind == CONV_FUSE) ? 1 : 9;
     const double px = (double)nimg * Hout * Wout;
     const double flops = 2.0 * taps * cw.cin * cw.cout * px;

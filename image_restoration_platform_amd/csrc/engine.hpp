@@ -123,6 +123,7 @@ private:
     int max_batch_ = 8;
     int num_lanes_ = 1;
     uint32_t flags_ = 0;
+    int prio_young_ = 1;
     int act_split_min_c_ = 128;  // ResBlock convs with C >= this read a pre-activated tensor (gn_apply_silu)
     int rb_tile_h_ = kRbTileH;  // 16: persistent pipelined conv_rb.hip; 8: conv_mfma.hip (IRE_CONV_V1=1)
     std::mutex mu_;
@@ -160,6 +161,10 @@ private:
     std::vector<void*> ws_allocs_;
 
     // debug / profile
+    // diagnostic stamps (IRE_RB_STAMPS, ablation builds)
+    unsigned long long* stamps_dev_ = nullptr;
+    int stamps_cout_ = 0;
+    bool stamps_resid_ = false, stamps_taken_ = false;
     bool capture_ = false;
     std::map<std::string, std::vector<float>> captured_;
     bool prof_on_ = false;
