@@ -141,6 +141,18 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         return it;
     };
 
+    // Stage descriptors are decoded ONCE per stage (three integer divisions) and kept in a 3-deep queue:
+    // sq0 = stage s (MFMA + epilogue), sq1 = stage s+1 (weights), sq2 = stage s+2 (prefetch, coefficients).
+    struct StageInfo { RbItem it; int kc; };
+    auto decode = [&](int s) -> StageInfo {
+        const int k = s / nkc;
+        StageInfo si;
+        si.it = item_of(k);
+        si.kc = s - k * nkc;
+        return si;
+    };
+    StageInfo sq0 = decode(0), sq1 = decode(min(1, S - 1)), sq2 = decode(min(2, S - 1));
+
     const unsigned short* src = reinterpret_cast<const unsigned short*>(a.in0);
     const int Cin = a.cin0;
 
@@ -159,9 +171,9 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
 
     // ---- helpers -------------------------------------------------------------------------------------
     const int cin_shift = 31 - __builtin_clz(Cin);                 // Cin is a power of two
-    auto load_stage = [&](int s, RbRegs& R) {
-        const RbItem it = item_of(s / nkc);
-        const int kc = s - (s / nkc) * nkc;
+    auto load_stage = [&](const StageInfo& si, RbRegs& R) {
+        const RbItem& it = si.it;
+        const int kc = si.kc;
         const int oy1 = it.ty * RB_TH - 1, ox1 = it.tx * RB_TW - 1;
         // wave-uniform image base (SGPR pair) + 32-bit per-lane byte offset
         const char* base = reinterpret_cast<const char*>(src) + (size_t)it.img * a.Hin * a.Win * Cin * 2 + kc * 64;
@@ -189,11 +201,11 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
     // at the stage top matters: vmcnt completes in order, so a late coefficient load would drag the previous
     // item's output stores into the wait.
     float* coef_lds = reinterpret_cast<float*>(smem + C::MAIN_BYTES + C::RED_BYTES);   // [2][32 ch][2]
-    auto fetch_coeffs = [&](int s) -> float4 {                   // lanes 0..15: 16 B each of the stage's 256 B
+    auto fetch_coeffs = [&](const StageInfo& si) -> float4 {     // lanes 0..15: 16 B each of the stage's 256 B
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (FUSED_ACT) {
-            const RbItem it = item_of(s / nkc);
-            const int kc = s - (s / nkc) * nkc;
+            const RbItem& it = si.it;
+            const int kc = si.kc;
             const float4* ab = reinterpret_cast<const float4*>(a.ab + (size_t)it.img * Cin + kc * 32);
             v = ab[tid & 15];
         }
@@ -239,9 +251,9 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         for (int d = 0; d < 4; ++d) tw[d] = transform_word(word_of(R.v[i], d), d, cA, cB);
         store_words(i, R, tw, lds_in);
     };
-    auto wslab = [&](int s) -> const uint4* {
-        const RbItem it = item_of(s / nkc);
-        const int kc = s - (s / nkc) * nkc;
+    auto wslab = [&](const StageInfo& si) -> const uint4* {
+        const RbItem& it = si.it;
+        const int kc = si.kc;
         return reinterpret_cast<const uint4*>(a.w) + ((size_t)it.nb * nkc + kc) * C::W_CHUNKS;
     };
 
@@ -325,12 +337,13 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
             asm volatile("" : "+v"(te));
             const int cc = te % NCC;
             const int oy0 = it.ty * RB_TH, ox0 = it.tx * RB_TW, cout0 = it.nb * NT;
+            const char* rbase = reinterpret_cast<const char*>(a.resid) + (size_t)it.img * a.Hout * a.Wout * a.cout * 2;   // uniform
 #pragma unroll
             for (int k = 0; k < C::OUT_ITERS; ++k) {
                 const int pix = (te + k * RB_THREADS) / NCC;
                 const int oy = min(oy0 + (pix >> 5), a.Hout - 1), ox = min(ox0 + (pix & 31), a.Wout - 1);
-                const size_t g = (((size_t)it.img * a.Hout + oy) * a.Wout + ox) * a.cout + cout0 + cc * 8;
-                rv[k] = *reinterpret_cast<const uint4*>(a.resid + g);
+                const unsigned off = ((unsigned)((oy * a.Wout + ox) * a.cout + cout0) << 1) + (unsigned)(cc * 16);
+                rv[k] = *reinterpret_cast<const uint4*>(rbase + off);
             }
         }
     };
@@ -347,7 +360,8 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
         const bool inb = valid && oy < a.Hout && ox < a.Wout;
         const uint4 o = reinterpret_cast<const uint4*>(lds_ob)[pix * NCC + (cc ^ (pix & (NCC - 1)))];
-        const size_t g = (((size_t)it.img * a.Hout + oy) * a.Wout + ox) * a.cout + cout0 + cc * 8;
+        char* obase = reinterpret_cast<char*>(a.out) + (size_t)it.img * a.Hout * a.Wout * a.cout * 2;   // uniform
+        const unsigned off = ((unsigned)((oy * a.Wout + ox) * a.cout + cout0) << 1) + (unsigned)(cc * 16);
         unsigned w[4] = {o.x, o.y, o.z, o.w};
         if constexpr (RESID && !(DBG & 4)) {
             const unsigned rw[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w};
@@ -355,15 +369,23 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
             for (int d = 0; d < 4; ++d)
                 w[d] = rb_pack(rb_lo(w[d]) + rb_lo(rw[d]), rb_hi(w[d]) + rb_hi(rw[d]));
         }
+        // GroupNorm partial sums of the final bf16 values: v_dot2c_f32_bf16 sums a bf16 pair (x (1,1)) or its squares
+        // (x itself) into fp32 in one instruction; out-of-image pixels (and the empty first stage) are deselected.
+        {
+            const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+            float ts0 = 0.f, tq0 = 0.f, ts1 = 0.f, tq1 = 0.f;
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {                      // out-of-image pixels do not count in the statistics
-            const float f0 = inb ? rb_lo(w[d]) : 0.f, f1 = inb ? rb_hi(w[d]) : 0.f;
-            if (d < 2) { ds.sA += f0 + f1; ds.qA += f0 * f0 + f1 * f1; }
-            else { ds.sB += f0 + f1; ds.qB += f0 * f0 + f1 * f1; }
+            for (int d = 0; d < 4; ++d) {
+                const bf16x2_t wv = __builtin_bit_cast(bf16x2_t, w[d]);
+                if (d < 2) { ts0 = __builtin_amdgcn_fdot2_f32_bf16(wv, ones, ts0, false); tq0 = __builtin_amdgcn_fdot2_f32_bf16(wv, wv, tq0, false); }
+                else { ts1 = __builtin_amdgcn_fdot2_f32_bf16(wv, ones, ts1, false); tq1 = __builtin_amdgcn_fdot2_f32_bf16(wv, wv, tq1, false); }
+            }
+            ds.sA += inb ? ts0 : 0.f; ds.qA += inb ? tq0 : 0.f;
+            ds.sB += inb ? ts1 : 0.f; ds.qB += inb ? tq1 : 0.f;
         }
         if (inb) {
-            if constexpr (DBG & 4) { if (w[0] == 0x12345678u) a.out[g] = 1; }
-            else *reinterpret_cast<uint4*>(a.out + g) = make_uint4(w[0], w[1], w[2], w[3]);
+            if constexpr (DBG & 4) { if (w[0] == 0x12345678u) obase[off] = 1; }
+            else *reinterpret_cast<uint4*>(obase + off) = make_uint4(w[0], w[1], w[2], w[3]);
         }
     };
     auto drain_finish = [&](const RbItem& it, bool valid, DrainStats& ds) {
@@ -393,7 +415,6 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         RbRegs& Rn = PAR ? R0 : R1;   // holds stage s+1 (loaded during stage s-1)
         RbRegs& Rf = PAR ? R1 : R0;   // free: receives stage s+2
         // no branches in the stage body: the last stages redo harmless work on clamped stage indices
-        const int s1 = min(s + 1, S - 1), s2 = min(s + 2, S - 1);
 
         // (1) coefficients of stage s+1 first, then (3) the input prefetch of stage s+2, so that waiting
         // for (1) never waits for (3) (VMEM returns in issue order)
@@ -404,15 +425,15 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         for (int i = 0; i < RB_IN_ITERS; ++i) asm volatile("" : "+v"(Rn.v[i].x), "+v"(Rn.v[i].y), "+v"(Rn.v[i].z), "+v"(Rn.v[i].w));
         float cA[8], cB[8];
         load_coeffs(s & 1, cA, cB);                 // coefficients of stage s+1's data (slot written last stage)
-        float4 cnext = fetch_coeffs(s2);            // for the data of stage s+2, transformed during stage s+1
-        load_stage(s2, Rf);
+        float4 cnext = fetch_coeffs(sq2);           // for the data of stage s+2, transformed during stage s+1
+        load_stage(sq2, Rf);
         uint4 drv[C::OUT_ITERS];                    // deferred epilogue: residual of the parked item
         DrainStats dst{0.f, 0.f, 0.f, 0.f};
         if constexpr (C::DEFER) drain_load_resid(pend, drv);
 
-        if (s - (s / nkc) * nkc == 0) zero_acc();   // new item (not in the epilogue: 64 dead registers there)
+        if (sq0.kc == 0) zero_acc();   // new item (not in the epilogue: 64 dead registers there)
         // (4) 18 MFMA k-steps from the current buffer, the s+1 transform interleaved between groups
-        const int wsel = WRES ? ((s - (s / nkc) * nkc) * C::W_BYTES) : 0;   // resident: slab of this kc
+        const int wsel = WRES ? (sq0.kc * C::W_BYTES) : 0;   // resident: slab of this kc
         const unsigned char* wb = w_cur + wsel + b_off;
         const unsigned char* ib = reinterpret_cast<const unsigned char*>(in_cur);
         unsigned tw[4];
@@ -461,7 +482,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
                 // it.  Inline asm on purpose: with the builtin hipcc orders every later ds_write after the DMA with
                 // a vmcnt(0) (same LDS array => may alias), which would also drain the s+2 input prefetch.
                 if (st == 0) {
-                    const unsigned char* ws = reinterpret_cast<const unsigned char*>(wslab(s1));
+                    const unsigned char* ws = reinterpret_cast<const unsigned char*>(wslab(sq1));
                     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
                     const unsigned w_nxt_lds = smem_lds + (unsigned)(w_nxt - smem);
 #pragma unroll
@@ -489,7 +510,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         if constexpr (!WRES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(s, 2);
         // (6) last k-chunk of the item: epilogue
-        const int kc = s - (s / nkc) * nkc;
+        const int kc = sq0.kc;
         if constexpr (C::DEFER) {
             // every stage ends an item (nkc == 1).  The previous item's tile was drained inside the loop above;
             // park this item's tile in O for the next stage.
@@ -497,11 +518,11 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
             __syncthreads();                                   // all drains of O and all reads of buf[cur] are done
             stamp(s, 3);
             flush_stats();
-            const RbItem it = item_of(s);
+            const RbItem it = sq0.it;
             acc_to_lds(it, smem + C::O_OFF);
             pend = it; pend_valid = true;
         } else if (kc == nkc - 1) {
-            const RbItem it = item_of(s / nkc);
+            const RbItem it = sq0.it;
             uint4 rv[C::OUT_ITERS];
             drain_load_resid(it, rv);                          // before the barrier: covered by the wait for the slow half
             __syncthreads();                                   // every wave is done reading buf[cur]
@@ -519,20 +540,21 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         // (7) stage barrier: buf[nxt] complete, buf[cur] (and red[]) free
         __syncthreads();
         stamp(s, 5);
+        sq0 = sq1; sq1 = sq2; sq2 = decode(min(s + 3, S - 1));
     };
 
     // ---- prologue: stage 0 into buffer 0, stage 1 into registers --------------------------------------
     {
         float* bias_lds = reinterpret_cast<float*>(smem + C::MAIN_BYTES + C::RED_BYTES + C::COEF_BYTES);
         if (tid < a.cout) bias_lds[tid] = a.bias[tid];         // off the VMEM queue for good
-        put_coeffs(1, fetch_coeffs(0));                       // slot 1 plays "stage -1": transform of stage 0's data
-        load_stage(0, R0);
+        put_coeffs(1, fetch_coeffs(sq0));                       // slot 1 plays "stage -1": transform of stage 0's data
+        load_stage(sq0, R0);
         if (WRES) {   // whole weight set of this n-block stays in LDS (nblocks == 1)
             const uint4* ws = reinterpret_cast<const uint4*>(a.w);
             uint4* wd = reinterpret_cast<uint4*>(smem + C::W_OFF0);
             for (int i = tid; i < C::W_CHUNKS * nkc; i += RB_THREADS) wd[i] = ws[i];
         } else {
-            const uint4* ws = wslab(0);
+            const uint4* ws = wslab(sq0);
             uint4* wd = reinterpret_cast<uint4*>(smem + C::W_OFF0);
             for (int i = tid; i < C::W_CHUNKS; i += RB_THREADS) wd[i] = ws[i];
         }
@@ -542,8 +564,8 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         uint4* in0 = reinterpret_cast<uint4*>(smem);
 #pragma unroll
         for (int i = 0; i < RB_IN_ITERS; ++i) store_chunk(i, R0, cA, cB, in0);
-        put_coeffs(0, fetch_coeffs(min(1, S - 1)));           // slot 0: read at the top of stage 0 for stage 1's data
-        load_stage(min(1, S - 1), R1);
+        put_coeffs(0, fetch_coeffs(sq1));           // slot 0: read at the top of stage 0 for stage 1's data
+        load_stage(sq1, R1);
     }
     __syncthreads();
 
