@@ -228,9 +228,16 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
     auto word_of = [&](const uint4& v, int d) -> unsigned { return d == 0 ? v.x : d == 1 ? v.y : d == 2 ? v.z : v.w; };
     auto transform_word = [&](unsigned w, int d, const float (&cA)[8], const float (&cB)[8]) -> unsigned {
         if constexpr (FUSED_ACT) {
-            const float y0 = __builtin_fmaf(rb_lo(w), cA[2 * d], cB[2 * d]);
-            const float y1 = __builtin_fmaf(rb_hi(w), cA[2 * d + 1], cB[2 * d + 1]);
-            return rb_pack(rb_silu(y0), rb_silu(y1));
+            // two channels at a time in packed f32 (v_pk_fma/mul/add_f32): y = x*A + B ; silu(y) = y / (1 + 2^(-y log2 e))
+            const f32x2_t x = {rb_lo(w), rb_hi(w)};
+            const f32x2_t A = {cA[2 * d], cA[2 * d + 1]}, B = {cB[2 * d], cB[2 * d + 1]};
+            const f32x2_t y = __builtin_elementwise_fma(x, A, B);
+            const f32x2_t t = y * (-1.4426950408889634f);
+            f32x2_t e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+            e = e + 1.0f;
+            const f32x2_t rinv = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+            const f32x2_t sv = y * rinv;
+            return rb_pack(sv.x, sv.y);
         } else {
             return w;                                  // input was activated by gn_apply_silu (gn.hip)
         }
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         DrainStats dst{0.f, 0.f, 0.f, 0.f};
         if constexpr (C::DEFER) drain_load_resid(pend, drv);
 
-        if (sq0.kc == 0) zero_acc();   // new item (not in the epilogue: 64 dead registers there)
+        if constexpr (!WRES) { if (sq0.kc == 0) zero_acc(); }   // WRES (nkc == 1): step 0 accumulates onto an inline 0   // new item (not in the epilogue: 64 dead registers there)
         // (4) 18 MFMA k-steps from the current buffer, the s+1 transform interleaved between groups
         const int wsel = WRES ? (sq0.kc * C::W_BYTES) : 0;   // resident: slab of this kc
         const unsigned char* wb = w_cur + wsel + b_off;
@@ -456,12 +463,17 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
 #pragma unroll
         for (int st = 0; st < RB_NSTEPS; ++st) {
             if (st + 1 < RB_NSTEPS) read_frags(st + 1, bfr[(st + 1) & 1], afr[(st + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);   // keep the reads AHEAD of this step's MFMAs (hipcc sinks them otherwise)
             if constexpr (!(DBG & 3)) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int j = 0; j < NTL; ++j)
-                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[st & 1][j], afr[st & 1][m], acc[m][j], 0, 0, 0);  // D[cout][pixel]
+                    {
+                        f32x16_t cin = acc[m][j];
+                        if constexpr (WRES) { if (st == 0) cin = f32x16_t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[st & 1][j], afr[st & 1][m], cin, 0, 0, 0);  // D[cout][pixel]
+                    }
             } else if constexpr (!(DBG & 2)) {
 #pragma unroll
                 for (int j = 0; j < NTL; ++j) asm volatile("" :: "v"(bfr[st & 1][j]));   // keep the reads alive
