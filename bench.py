@@ -31,7 +31,7 @@ def cpu_baseline(size, budget_s=25.0):
     from image_restoration_platform_amd import synth, weights
     from oracle import classifier as oc
     from oracle import restorenet as onet
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)   # a 1-GPU box's CPU share; more threads only oversubscribe
     torch.set_num_threads(cores)
     img = synth.batch(1, size, size)
     w = weights.generate(0)
@@ -52,9 +52,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("IRE_STREAMS", "2")))
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("IRE_STREAMS", "1")),
+                    help="lanes (HIP streams) per engine; 2 is ~3 %% faster but overlapping kernels would skew the per-kernel event timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the in-engine HIP-event kernel timing")
+    ap.add_argument("--profile-all", action="store_true", help="time every kernel family (more events, ~5 %% slower)")
     args = ap.parse_args()
 
     import numpy as np
@@ -94,7 +96,7 @@ def main():
 
     if not args.no_profile:
         eng.profile_reset()
-        eng.profile_enable(True)
+        eng.profile_enable(1 if args.profile_all else 2)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -105,7 +107,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = None
     if not args.no_profile:
-        eng.profile_enable(False)
+        eng.profile_enable(0)
         prof = {f: eng.profile_query(f) for f in ("conv3x3", "conv1x1", "stem", "head", "classifier", "gn_finalize", "all")}
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)

@@ -297,7 +297,7 @@ int ire_profile_enable(ire_engine* e, int on) {
     return guarded([&] {
         Engine& E = eng(e);
         std::lock_guard<std::mutex> lk(E.mutex());
-        E.profile_enable(on != 0);
+        E.profile_enable(on);
     });
 }
 

@@ -57,6 +57,31 @@ __device__ __forceinline__ void rb_glds16(const void* gsrc, unsigned lds_dst_uni
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
 }
 
+// Sum over the lanes that share (lane % NCC), NCC in {4, 8}: row rotations (DPP) inside the 16-lane rows, then
+// the two permlane swaps across rows / wave halves.  Every lane ends with the total; fixed order => deterministic.
+// The swaps are inline asm on purpose: with the builtins hipcc (ROCm 7.2) folds the two results into one register
+// when both inputs are the same value (verified in the ISA); the two v_nop are the VALU-write -> permlane wait states.
+template <int N> __device__ __forceinline__ float rb_ror_add(float v) {
+    const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false);
+    return v + __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ float rb_swap16_add(float v) {
+    float x = v, y = v;
+    asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return x + y;
+}
+__device__ __forceinline__ float rb_swap32_add(float v) {
+    float x = v, y = v;
+    asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return x + y;
+}
+template <int NCC> __device__ __forceinline__ float rb_group_sum(float v) {
+    if constexpr (NCC == 4) v = rb_ror_add<4>(v);
+    v = rb_ror_add<8>(v);
+    v = rb_swap16_add(v);
+    return rb_swap32_add(v);
+}
+
 struct RbItem {
     int img, ty, tx, nb, tile;  // tile = ty*tiles_x + tx
 };
@@ -112,7 +137,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         if constexpr (DBG & 16) {
             const unsigned long long t = __builtin_amdgcn_s_memtime();
             if (a.stamps && lane == 0 && (wave == 0 || wave == 4) && blockIdx.x < 8 && s < 64)
-                a.stamps[(((size_t)blockIdx.x * 2 + (wave >> 2)) * 64 + s) * 6 + k] = t;
+                a.stamps[(((size_t)blockIdx.x * 2 + (wave >> 2)) * 64 + s) * 10 + k] = t;
         }
     };
 
@@ -397,11 +422,8 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
     };
     auto drain_finish = [&](const RbItem& it, bool valid, DrainStats& ds) {
         if (!valid) return;                                    // wave-uniform
-#pragma unroll
-        for (int off = NCC; off < 64; off <<= 1) {
-            ds.sA += __shfl_xor(ds.sA, off, 64); ds.qA += __shfl_xor(ds.qA, off, 64);
-            ds.sB += __shfl_xor(ds.sB, off, 64); ds.qB += __shfl_xor(ds.qB, off, 64);
-        }
+        ds.sA = rb_group_sum<NCC>(ds.sA); ds.qA = rb_group_sum<NCC>(ds.qA);
+        ds.sB = rb_group_sum<NCC>(ds.sB); ds.qB = rb_group_sum<NCC>(ds.qB);
         if (lane < NCC) {
             float* d = red + (wave * NCC + lane) * 4;
             d[0] = ds.sA; d[1] = ds.qA; d[2] = ds.sB; d[3] = ds.qB;
@@ -534,6 +556,9 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
             acc_to_lds(it, smem + C::O_OFF);
             pend = it; pend_valid = true;
         } else if (kc == nkc - 1) {
+            // no priority skew inside the barrier-delimited epilogue (the unprioritised half took 3x longer here)
+            const bool young = a.prio_young && __builtin_amdgcn_readfirstlane(wave) >= 4;
+            if (young) __builtin_amdgcn_s_setprio(0);
             const RbItem it = sq0.it;
             uint4 rv[C::OUT_ITERS];
             drain_load_resid(it, rv);                          // before the barrier: covered by the wait for the slow half
@@ -542,11 +567,15 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
             flush_stats();                                     // (red[] of the previous item is complete)
             unsigned char* lds_ob = smem + PAR * C::BUF_STRIDE;  // out tile in buf[cur]
             acc_to_lds(it, lds_ob);
+            stamp(s, 6);
             __syncthreads();
+            stamp(s, 7);
             DrainStats ds{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < C::OUT_ITERS; ++k) drain_chunk(k, it, true, lds_ob, rv, ds);
+            stamp(s, 8);
             drain_finish(it, true, ds);
+            if (young) __builtin_amdgcn_s_setprio(1);
         }
         stamp(s, 4);
         // (7) stage barrier: buf[nxt] complete, buf[cur] (and red[]) free

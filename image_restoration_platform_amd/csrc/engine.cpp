@@ -81,8 +81,8 @@ Engine::Engine(const ire_config& cfg) {
     IRE_HIP(hipMemcpy(d_inv, kGreyInv, sizeof(kGreyInv), hipMemcpyHostToDevice));
     tables_ = ClassifierTables{d_lin, d_thr, d_inv};
     if (stamps_cout_) {
-        stamps_dev_ = (unsigned long long*)dalloc(8 * 2 * 64 * 6 * 8);
-        IRE_HIP(hipMemset(stamps_dev_, 0, 8 * 2 * 64 * 6 * 8));
+        stamps_dev_ = (unsigned long long*)dalloc(8 * 2 * 64 * 10 * 8);
+        IRE_HIP(hipMemset(stamps_dev_, 0, 8 * 2 * 64 * 10 * 8));
     }
 
     if (cfg.weights_path && cfg.weights_path[0]) load_weights_file(cfg.weights_path);
@@ -92,18 +92,20 @@ Engine::~Engine() {
     (void)hipSetDevice(device_);
     (void)hipDeviceSynchronize();
     if (stamps_dev_) {   // diagnostic dump: per-stage phase durations (s_memtime ticks = shader clocks / 100 MHz ref? printed raw)
-        std::vector<unsigned long long> h(8 * 2 * 64 * 6);
+        std::vector<unsigned long long> h(8 * 2 * 64 * 10);
         (void)hipMemcpy(h.data(), stamps_dev_, h.size() * 8, hipMemcpyDeviceToHost);
         const char* names[5] = {"top->mfma_loop_end", "->vmcnt0", "->epi_barrier1", "->epilogue_end", "->stage_barrier"};
         for (int wg = 0; wg < 2; ++wg)
             for (int wv = 0; wv < 2; ++wv) {
                 std::fprintf(stderr, "[stamps] wg %d wave %d (ticks per segment; -1 = not taken)\n", wg, wv * 4);
                 for (int s = 0; s < 40; ++s) {
-                    const unsigned long long* t = &h[(((size_t)wg * 2 + wv) * 64 + s) * 6];
+                    const unsigned long long* t = &h[(((size_t)wg * 2 + wv) * 64 + s) * 10];
                     if (!t[0]) continue;
                     long long d01 = (long long)(t[1] - t[0]), d12 = (long long)(t[2] - t[1]);
                     long long d23 = t[3] ? (long long)(t[3] - t[2]) : -1, d34 = t[3] ? (long long)(t[4] - t[3]) : (long long)(t[4] - t[2]);
                     long long d45 = (long long)(t[5] - t[4]);
+                    if (t[6]) std::fprintf(stderr, "      epilogue detail: barrier1->acc_to_lds=%lld ->barrier2=%lld ->drain_loop=%lld ->finish=%lld\n",
+                                           (long long)(t[6] - t[3]), (long long)(t[7] - t[6]), (long long)(t[8] - t[7]), (long long)(t[4] - t[8]));
                     std::fprintf(stderr, "  s%02d %s=%lld %s=%lld %s=%lld %s=%lld %s=%lld | stage=%lld\n", s, names[0], d01, names[1], d12,
                                  names[2], d23, names[3], d34, names[4], d45, (long long)(t[5] - t[0]));
                 }
@@ -354,7 +356,8 @@ void Engine::ensure_workspace(int n, int h, int w) {
 // profiler (HIP events on the stream the kernel is launched on)
 // ------------------------------------------------------------------------------------------------
 void Engine::prof_begin(int fam, hipStream_t s, double flops, double bytes) {
-    if (!prof_on_) return;
+    prof_open_ = prof_on_ == 1 || (prof_on_ == 2 && fam == FAM_CONV3);   // mode 2: dominant family only (fewer events)
+    if (!prof_open_) return;
     ProfRec r;
     r.fam = fam; r.flops = flops; r.bytes = bytes;
     auto get = [&]() {
@@ -368,7 +371,7 @@ void Engine::prof_begin(int fam, hipStream_t s, double flops, double bytes) {
     prof_.push_back(r);
 }
 void Engine::prof_end(hipStream_t s) {
-    if (!prof_on_) return;
+    if (!prof_open_) return;
     IRE_HIP(hipEventRecord(prof_.back().e1, s));
 }
 void Engine::prof_collect() {
@@ -382,7 +385,7 @@ void Engine::prof_collect() {
     }
     prof_.clear();
 }
-void Engine::profile_enable(bool on) { prof_collect(); prof_on_ = on; }
+void Engine::profile_enable(int mode) { prof_collect(); prof_on_ = mode; }
 void Engine::profile_reset() {
     prof_collect();
     for (int i = 0; i < FAM_COUNT; ++i) { prof_ms_[i] = prof_flops_[i] = prof_bytes_[i] = 0; prof_n_[i] = 0; }

@@ -94,7 +94,7 @@ public:
     void debug_capture(bool on) { capture_ = on; captured_.clear(); }
     bool debug_activation(const std::string& name, float* out, size_t* count);
 
-    void profile_enable(bool on);
+    void profile_enable(int mode);   // 0 off, 1 every kernel family, 2 the 3x3 conv family only
     void profile_reset();
     void profile_query(int fam, double* ms, int64_t* launches, double* flops, double* bytes);
 
@@ -123,7 +123,7 @@ private:
     int max_batch_ = 8;
     int num_lanes_ = 1;
     uint32_t flags_ = 0;
-    int prio_young_ = 1;
+    int prio_young_ = 0;          // static s_setprio for waves 4-7 of conv_rb (A/B'd: it only swaps which half waits)
     int act_split_min_c_ = 128;  // ResBlock convs with C >= this read a pre-activated tensor (gn_apply_silu)
     int rb_tile_h_ = kRbTileH;  // 16: persistent pipelined conv_rb.hip; 8: conv_mfma.hip (IRE_CONV_V1=1)
     std::mutex mu_;
@@ -167,7 +167,8 @@ private:
     bool stamps_resid_ = false, stamps_taken_ = false;
     bool capture_ = false;
     std::map<std::string, std::vector<float>> captured_;
-    bool prof_on_ = false;
+    int prof_on_ = 0;
+    bool prof_open_ = false;
     std::vector<ProfRec> prof_;
     std::vector<hipEvent_t> ev_pool_;
     double prof_ms_[FAM_COUNT] = {}, prof_flops_[FAM_COUNT] = {}, prof_bytes_[FAM_COUNT] = {};

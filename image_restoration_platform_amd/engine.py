@@ -187,8 +187,9 @@ class Engine:
         self._check(self._lib.ire_debug_activation(self._h, name.encode(), _ptr(out), ctypes.byref(cnt)))
         return out
 
-    def profile_enable(self, on=True):
-        self._check(self._lib.ire_profile_enable(self._h, int(on)))
+    def profile_enable(self, mode=1):
+        """0 off, 1 every kernel family, 2 the 3x3 conv family only (fewest HIP events)."""
+        self._check(self._lib.ire_profile_enable(self._h, int(mode)))
 
     def profile_reset(self):
         self._check(self._lib.ire_profile_reset(self._h))
