@@ -48,6 +48,9 @@ void conv_launch(ConvKind kind, const ConvArgs& a, hipStream_t stream);
 constexpr int kRbTileH = 16;
 // fused_act: apply y = silu(x*A+B) while staging (a.ab); otherwise the input is already activated.
 void conv_rb_launch(bool resid, bool fused_act, const ConvArgs& a, hipStream_t stream);
+// One-wave-per-SIMD variant for C >= 128 ResBlock convs on a pre-activated input (conv_w4.hip):
+// a.nkc = Cin/16, a.nblocks = cout/128, a.w = slabs [nblock][kc16][tap*2 + c8][128][8], 16x32 tiles.
+void conv_w4_launch(bool resid, const ConvArgs& a, hipStream_t stream);
 // CONV_UP through the same pipelined kernel (Hin/Win = low-res source, Hout/Wout = 2x; a.stats = nullptr).
 void conv_up_launch(const ConvArgs& a, hipStream_t stream);
 

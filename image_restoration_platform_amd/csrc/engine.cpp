@@ -57,6 +57,7 @@ Engine::Engine(const ire_config& cfg) {
     if (const char* v = std::getenv("IRE_CONV_V1")) rb_tile_h_ = (v[0] == '1') ? 8 : kRbTileH;
     if (const char* v = std::getenv("IRE_ACT_SPLIT_MINC")) act_split_min_c_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_RB_PRIO")) prio_young_ = std::atoi(v);
+    if (const char* v = std::getenv("IRE_W4")) use_w4_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_RB_STAMPS")) {   // diagnostic: "<cout>[r]" = stamp the first such ResBlock conv
         stamps_cout_ = std::atoi(v);
         stamps_resid_ = std::strchr(v, 'r') != nullptr;
@@ -183,6 +184,24 @@ ConvW Engine::make_conv(ConvKind kind, const std::string& wname, const std::stri
     c.d_w = (unsigned short*)dalloc(arr.size() * 2);
     net_.allocs.push_back(c.d_w);
     IRE_HIP(hipMemcpy(c.d_w, arr.data(), arr.size() * 2, hipMemcpyHostToDevice));
+    if ((kind == CONV_RB1 || kind == CONV_RB2) && cout >= 128 && cin % 16 == 0 && cout % 128 == 0) {
+        // conv_w4.hip slabs: [nblock (128 couts)][kc16][kk = tap*2 + c8][128][8]
+        const int nb4 = cout / 128, nk4 = cin / 16;
+        std::vector<unsigned short> arr4((size_t)nb4 * nk4 * 18 * 128 * 8, 0);
+        for (int nb = 0; nb < nb4; ++nb)
+            for (int kc = 0; kc < nk4; ++kc)
+                for (int kk = 0; kk < 18; ++kk) {
+                    const int tap = kk >> 1, c8 = kk & 1;
+                    for (int n = 0; n < 128; ++n)
+                        for (int e = 0; e < 8; ++e) {
+                            const int co = nb * 128 + n, ci = kc * 16 + c8 * 8 + e;
+                            arr4[((((size_t)nb * nk4 + kc) * 18 + kk) * 128 + n) * 8 + e] = f32_to_bf16(W[((size_t)co * cin + ci) * 9 + tap]);
+                        }
+                }
+        c.d_w4 = (unsigned short*)dalloc(arr4.size() * 2);
+        net_.allocs.push_back(c.d_w4);
+        IRE_HIP(hipMemcpy(c.d_w4, arr4.data(), arr4.size() * 2, hipMemcpyHostToDevice));
+    }
     std::vector<float> bias(cout_pad, 0.f);
     std::memcpy(bias.data(), bi->second.second.data(), sizeof(float) * cout);
     c.d_bias = (float*)dalloc(bias.size() * 4);
@@ -466,7 +485,11 @@ void Engine::launch_conv(Lane& L, const ConvW& cw, const void* in0, const void* 
     else if (cw.kind == CONV_STEM) fam = FAM_STEM;
     else if (cw.kind == CONV_HEAD) fam = FAM_HEAD;
     prof_begin(fam, L.stream, flops, bytes);
-    if (up_rb) conv_up_launch(a, L.stream);
+    const bool w4 = rb && rb_tile_h_ == kRbTileH && use_w4_ && ab == nullptr && cw.d_w4 != nullptr;
+    if (w4) {
+        a.w = cw.d_w4; a.nkc = cw.cin / 16; a.nblocks = cw.cout / 128;
+        conv_w4_launch(cw.kind == CONV_RB2, a, L.stream);
+    } else if (up_rb) conv_up_launch(a, L.stream);
     else if (rb && rb_tile_h_ == kRbTileH) conv_rb_launch(cw.kind == CONV_RB2, /*fused_act=*/ab != nullptr, a, L.stream);
     else conv_launch(cw.kind, a, L.stream);
     prof_end(L.stream);

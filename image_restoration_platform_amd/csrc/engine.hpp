@@ -26,6 +26,7 @@ struct ConvW {
     int cin0 = 0, cin1 = 0;      // channels per pixel of the two sources
     int nt = 0, nblocks = 0, nkc = 0, kc_split = 0;
     unsigned short* d_w = nullptr;
+    unsigned short* d_w4 = nullptr;  // second arrangement for conv_w4.hip (C >= 128 ResBlock convs): 16-channel stages, 128-cout blocks
     float* d_bias = nullptr;
 };
 struct GNW {
@@ -123,6 +124,7 @@ private:
     int max_batch_ = 8;
     int num_lanes_ = 1;
     uint32_t flags_ = 0;
+    int use_w4_ = 0;              // IRE_W4=1: C >= 128 ResBlock convs on conv_w4.hip (experimental; default conv_rb.hip)
     int prio_young_ = 0;          // static s_setprio for waves 4-7 of conv_rb (A/B'd: it only swaps which half waits)
     int act_split_min_c_ = 128;  // ResBlock convs with C >= this read a pre-activated tensor (gn_apply_silu)
     int rb_tile_h_ = kRbTileH;  // 16: persistent pipelined conv_rb.hip; 8: conv_mfma.hip (IRE_CONV_V1=1)
