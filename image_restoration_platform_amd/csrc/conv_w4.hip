@@ -27,13 +27,10 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
-constexpr int W4_THREADS = 256;
 constexpr int W4_TH = 16, W4_TW = 32, W4_IH = 18, W4_IW = 34;
 constexpr int W4_IN_CHUNKS = W4_IH * W4_IW * 2;                              // 1224 x 16 B (16 channels per pixel)
 constexpr int W4_IN_BYTES = (W4_IN_CHUNKS + 8) * 16;                          // + dummy slot (chunk slots past the tile)
-constexpr int W4_IN_ITERS = (W4_IN_CHUNKS + W4_THREADS - 1) / W4_THREADS;     // 5
 constexpr int W4_NSTEPS = 9;
-constexpr int W4_MT = 4;
 
 __device__ __forceinline__ unsigned w4_pack(float a, float b) {
     f32x2_t f = {a, b};
@@ -61,8 +58,10 @@ __device__ __forceinline__ float w4_swap32_add(float v) {
     asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
     return x + y;
 }
-// sum over lanes with equal (lane % 4): the drain handles 32-channel passes => 4 chunks per pixel
-__device__ __forceinline__ float w4_group_sum(float v) {
+// sum over the 64 lanes of the wave (every lane ends up with the total)
+__device__ __forceinline__ float w4_wave_sum(float v) {
+    v = w4_ror_add<1>(v);
+    v = w4_ror_add<2>(v);
     v = w4_ror_add<4>(v);
     v = w4_ror_add<8>(v);
     v = w4_swap16_add(v);
@@ -70,28 +69,33 @@ __device__ __forceinline__ float w4_group_sum(float v) {
 }
 
 struct W4Item { int img, ty, tx, nb, tile; };
-struct W4Regs { uint4 v[W4_IN_ITERS]; unsigned ok; };
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <int N> struct W4Regs { u32x4_t v[N]; unsigned ok; };   // native 128-bit tuples: one register quad per load
 
-template <int NT>
+// WAVES = 4: one wave per SIMD, wave tile 4 rows x NT couts (all 256 AGPRs are accumulators at NT = 128)
+// WAVES = 8: two waves per SIMD, wave tile 2 rows x NT couts (128 accumulators): a partner wave's MFMAs cover this wave's
+//            VMEM / LDS-DMA / epilogue issue slots, which a single wave per SIMD can only serialise
+template <int NT, int WAVES>
 struct W4Cfg {
+    static constexpr int THREADS = WAVES * 64;
+    static constexpr int MT = W4_TH / WAVES;
+    static constexpr int IN_ITERS = (W4_IN_CHUNKS + THREADS - 1) / THREADS;
     static constexpr int NTL = NT / 32;
     static constexpr int W_CHUNKS = W4_NSTEPS * 2 * NT;        // [tap][c8][NT] x 16 B
     static constexpr int W_BYTES = W_CHUNKS * 16;
-    static constexpr int W_ITERS = (W_CHUNKS + W4_THREADS - 1) / W4_THREADS;
-    static constexpr int BUF_STRIDE = W4_IN_BYTES + W_BYTES;   // [in | w]
-    static constexpr int MAIN_BYTES = 2 * BUF_STRIDE;
-    static constexpr int RED_BYTES = 4 * 4 * 4 * 4;            // [4 waves][4 cc][4] floats (one 32-channel pass)
+    static constexpr int W_ITERS = (W_CHUNKS + THREADS - 1) / THREADS;
+    static constexpr int W_BASE = 2 * W4_IN_BYTES;             // in[2] | w[3]
+    static constexpr int MAIN_BYTES = W_BASE + 3 * W_BYTES;
+    static constexpr int RED_BYTES = WAVES * 8 * 2 * 4;        // [waves][8 slots of 16 couts][sum, sumsq]
     static constexpr int BIAS_BYTES = 256 * 4;
     static constexpr int LDS_BYTES = MAIN_BYTES + RED_BYTES + BIAS_BYTES;
-    static constexpr int PASS_CHUNKS = W4_TH * W4_TW * 4;      // one 32-channel pass: 512 px x 4 chunks
-    static constexpr int OUT_ITERS = PASS_CHUNKS / W4_THREADS; // 8
-    static_assert(W4_TH * W4_TW * 32 * 2 <= BUF_STRIDE, "a 32-channel pass must fit in one stage buffer");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int NT, bool RESID, bool UPS, int DBG = 0>
-__global__ __launch_bounds__(W4_THREADS) void conv_w4_kernel(ConvArgs a) {
-    using C = W4Cfg<NT>;
+template <int NT, int WAVES, bool RESID, bool UPS, int DBG = 0>
+__global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
+    using C = W4Cfg<NT, WAVES>;
+    using Regs = W4Regs<C::IN_ITERS>;
     constexpr int NTL = C::NTL;
     __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
     const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -139,48 +143,50 @@ __global__ __launch_bounds__(W4_THREADS) void conv_w4_kernel(ConvArgs a) {
     // of the ds_write_b128 (4 pixels x 2 planes) are conflict-free too.
     constexpr int PLANE = (W4_IN_CHUNKS / 2) * 16;
     static_assert((PLANE / 4) % 32 == 16, "plane offset must be half a bank row");
-    const int a_base = h * PLANE + (wave * W4_MT * W4_IW + r) * 16;
+    const int a_base = h * PLANE + (wave * C::MT * W4_IW + r) * 16;
     const int b_off = (h * NT + r) * 16;
 
-    auto load_stage = [&](const StageInfo& si, W4Regs& R) {
+    // one 16-B chunk per thread and call: chunk idx = tid + i*256 of the (18 x 34 px) x 2 halves tile of stage si
+    auto load_chunk = [&](const StageInfo& si, int i, Regs& R) {
         const W4Item& it = si.it;
         const int oy1 = it.ty * W4_TH - 1, ox1 = it.tx * W4_TW - 1;
         const char* base = reinterpret_cast<const char*>(a.in0) + (size_t)it.img * a.Hin * a.Win * Cin * 2 + si.kc * 32;
-        R.ok = 0;
         int t2 = tid;
         asm volatile("" : "+v"(t2));
-#pragma unroll
-        for (int i = 0; i < W4_IN_ITERS; ++i) {
-            const int p = (t2 + i * W4_THREADS) >> 1;
-            const int py = p / W4_IW, px = p - py * W4_IW;
-            const int iy = oy1 + py, ix = ox1 + px;
-            const int HV = UPS ? a.Hout : a.Hin, WV = UPS ? a.Wout : a.Win;
-            const int cy = min(max(iy, 0), HV - 1), cx = min(max(ix, 0), WV - 1);
-            const bool ok = iy == cy && ix == cx;
-            const int sy = UPS ? (cy >> 1) : cy, sx = UPS ? (cx >> 1) : cx;
-            const unsigned off = ((unsigned)(sy * a.Win + sx) << (cin_shift + 1)) + (unsigned)(c8_fixed * 16);
-            if constexpr (!(DBG & 8)) R.v[i] = *reinterpret_cast<const uint4*>(base + off);
-            R.ok |= ok ? (1u << i) : 0u;
-        }
+        const int p = (t2 + i * C::THREADS) >> 1;
+        const int py = p / W4_IW, px = p - py * W4_IW;
+        const int iy = oy1 + py, ix = ox1 + px;
+        const int HV = UPS ? a.Hout : a.Hin, WV = UPS ? a.Wout : a.Win;
+        const int cy = min(max(iy, 0), HV - 1), cx = min(max(ix, 0), WV - 1);
+        const bool ok = iy == cy && ix == cx;
+        const int sy = UPS ? (cy >> 1) : cy, sx = UPS ? (cx >> 1) : cx;
+        const unsigned off = ((unsigned)(sy * a.Win + sx) << (cin_shift + 1)) + (unsigned)(c8_fixed * 16);
+        R.v[i] = *reinterpret_cast<const u32x4_t*>(base + off);
+        R.ok = (R.ok & ~(1u << i)) | (ok ? (1u << i) : 0u);
     };
-    auto store_chunk = [&](int i, const W4Regs& R, uint4* lds_in) {   // plain copy; zero padding outside the image
+    auto load_stage = [&](const StageInfo& si, Regs& R) {
+        R.ok = 0;
+#pragma unroll
+        for (int i = 0; i < C::IN_ITERS; ++i) load_chunk(si, i, R);
+    };
+    auto store_chunk = [&](int i, const Regs& R, uint4* lds_in) {   // plain copy; zero padding outside the image
         int t2 = tid;
         asm volatile("" : "+v"(t2));
-        const int idx = t2 + i * W4_THREADS;
+        const int idx = t2 + i * C::THREADS;
         const bool ok = (R.ok >> i) & 1u;
-        uint4 o;
-        o.x = ok ? R.v[i].x : 0u; o.y = ok ? R.v[i].y : 0u; o.z = ok ? R.v[i].z : 0u; o.w = ok ? R.v[i].w : 0u;
+        const u32x4_t zero = {0u, 0u, 0u, 0u};
+        const u32x4_t o = ok ? R.v[i] : zero;
         const int slot = c8_fixed * (W4_IN_CHUNKS / 2) + (idx >> 1);
-        lds_in[idx < W4_IN_CHUNKS ? slot : W4_IN_CHUNKS] = o;
+        reinterpret_cast<u32x4_t*>(lds_in)[idx < W4_IN_CHUNKS ? slot : W4_IN_CHUNKS] = o;
     };
     auto wslab = [&](const StageInfo& si) -> const unsigned char* {
         return reinterpret_cast<const unsigned char*>(a.w) + ((size_t)si.it.nb * nkc + si.kc) * C::W_BYTES;
     };
 
-    f32x16_t acc[W4_MT][NTL];
+    f32x16_t acc[C::MT][NTL];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int m = 0; m < W4_MT; ++m)
+        for (int m = 0; m < C::MT; ++m)
 #pragma unroll
             for (int j = 0; j < NTL; ++j)
 #pragma unroll
@@ -192,165 +198,189 @@ __global__ __launch_bounds__(W4_THREADS) void conv_w4_kernel(ConvArgs a) {
 
     int s = 0;
     auto stamp = [&](int k) {
-#ifdef IRE_W4_STAMPS
+#ifdef IRE_W4_TICKS
         const unsigned long long t = __builtin_amdgcn_s_memtime();
-        if (a.stamps && lane == 0 && (wave == 0 || wave == 3) && blockIdx.x < 8 && s < 64)
+        if (a.stamps && lane == 0 && (wave == 0 || wave == WAVES - 1) && blockIdx.x < 8 && s < 64)
             a.stamps[(((size_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 64 + s) * 10 + k] = t;
 #else
         (void)k;
 #endif
     };
-    W4Regs R0, R1;
-    auto compute = [&](auto par_tag) {
-        constexpr int PAR = decltype(par_tag)::value;
-        unsigned char* buf_cur = smem + PAR * C::BUF_STRIDE;
-        unsigned char* buf_nxt = smem + (PAR ^ 1) * C::BUF_STRIDE;
-        uint4* in_nxt = reinterpret_cast<uint4*>(buf_nxt);
-        W4Regs& Rn = PAR ? R0 : R1;   // stage s+1 data (loaded one stage ago)
-        W4Regs& Rf = PAR ? R1 : R0;   // receives stage s+2
-        stamp(0);
+    // residual prefetch state lives across the item's last stage: the first RD-1 groups are requested BEFORE that stage's
+    // MFMAs (k-steps 0..3 carry no other VMEM), so the epilogue finds them landed
+    constexpr int RD = 4;                            // residual groups in flight
+    uint4 rv[RD][C::MT];
+    unsigned offs[C::MT];
+    bool inb[C::MT];
+    int cout0_e = 0;
+    auto load_resid = [&](int g, uint4 (&dst)[C::MT]) {
+        if constexpr (RESID) {
+            const char* rbase = reinterpret_cast<const char*>(a.resid) + (size_t)sq0.it.img * a.Hout * a.Wout * a.cout * 2;
 #pragma unroll
-        for (int i = 0; i < W4_IN_ITERS; ++i) asm volatile("" : "+v"(Rn.v[i].x), "+v"(Rn.v[i].y), "+v"(Rn.v[i].z), "+v"(Rn.v[i].w));
-        load_stage(sq2, Rf);
-
-        const unsigned char* wb = buf_cur + W4_IN_BYTES + b_off;
-        const unsigned char* ib = buf_cur;
-        bf16x8_t bfr[2][NTL], afr[2][W4_MT];
-        auto read_frags = [&](int st, bf16x8_t (&bf)[NTL], bf16x8_t (&af)[W4_MT]) {
+            for (int m = 0; m < C::MT; ++m)
+                dst[m] = *reinterpret_cast<const uint4*>(rbase + offs[m] + (unsigned)((g >> 1) * 64 + (g & 1) * 32));
+        }
+    };
+    auto epi_prefetch = [&]() {
+        const W4Item it = sq0.it;
+        int r_e = r, h_e = h, w_e = wave;
+        asm volatile("" : "+v"(r_e), "+v"(h_e), "+v"(w_e));
+        cout0_e = it.nb * NT;
+        const int oyb = it.ty * W4_TH + w_e * C::MT, ox = it.tx * W4_TW + r_e;
+        const bool colok = ox < a.Wout;
+        const int oxc = min(ox, a.Wout - 1);
+#pragma unroll
+        for (int m = 0; m < C::MT; ++m) {
+            const int oy = oyb + m;
+            inb[m] = colok && oy < a.Hout;
+            offs[m] = ((unsigned)((min(oy, a.Hout - 1) * a.Wout + oxc) * a.cout + cout0_e) << 1) + (unsigned)(h_e * 16);
+        }
+#pragma unroll
+        for (int g = 0; g + 1 < RD; ++g) load_resid(g, rv[g]);
+    };
+    // ---- one stage = 16 input channels: 9 k-steps (taps) of 16 MFMAs.  Pipeline (s = this stage):
+    //   * weights: three LDS slabs; the slab of stage s+2 is fetched by LDS-DMA during stage s (k-steps 4..8)
+    //   * input:   two LDS tiles; one register set R holds stage s+1 (loaded during stage s-1); during k-steps 4..8 chunk i
+    //              goes R -> LDS tile (s+1)&1 and R.v[i] is reloaded with stage s+2
+    //   * k-steps 0..3 issue no VMEM at all; the single wait (vmcnt(0) at k-step 4) therefore only sees operations issued
+    //     at least four k-steps earlier, and nothing is waited for at the stage end but the barrier.
+    Regs R;
+    int widx = 0;                                   // weight slab of the current stage (s % 3)
+    int par = 0;                                    // input tile of the current stage (s & 1)
+    // ONE stage body in the loop (tile parity and slab index are run-time offsets): unrolling stage pairs made the
+    // allocator park the reloaded R.v[i] in different registers per copy and "fix" that with vmcnt(0) + v_mov after each load
+    auto compute = [&](auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;   // the item's last stage: residual prefetch in flight
+        const unsigned char* ib = smem + par * W4_IN_BYTES;
+        uint4* in_nxt = reinterpret_cast<uint4*>(smem + (par ^ 1) * W4_IN_BYTES);
+        const unsigned char* wb = smem + C::W_BASE + widx * C::W_BYTES + b_off;
+        const int w2 = widx == 0 ? 2 : widx - 1;    // (s + 2) % 3
+        const unsigned w_dst_lds = smem_lds + C::W_BASE + w2 * C::W_BYTES;
+        stamp(0);
+        bf16x8_t bfr[2][NTL], afr[2][C::MT];
+        auto read_frags = [&](int st, bf16x8_t (&bf)[NTL], bf16x8_t (&af)[C::MT]) {
             const int ky = st / 3, kx = st - ky * 3;
 #pragma unroll
             for (int j = 0; j < NTL; ++j)
                 bf[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wb + (2 * st * NT + j * 32) * 16));
 #pragma unroll
-            for (int m = 0; m < W4_MT; ++m)
+            for (int m = 0; m < C::MT; ++m)
                 af[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ib + a_base + ((m + ky) * W4_IW + kx) * 16));
         };
         read_frags(0, bfr[0], afr[0]);
 #pragma unroll
         for (int st = 0; st < W4_NSTEPS; ++st) {
             if (st + 1 < W4_NSTEPS && !(DBG & 2)) read_frags(st + 1, bfr[(st + 1) & 1], afr[(st + 1) & 1]);
+            if (st == 4) {
+                // everything issued during the previous stage (R loads, slab s+1, epilogue stores) has had >= 4 k-steps
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < C::IN_ITERS; ++i) asm volatile("" : "+v"(R.v[i]));
+                if constexpr (LAST && RESID) {      // landed as well: tell the compiler, or it re-waits with its own (short) count
+#pragma unroll
+                    for (int g = 0; g + 1 < RD; ++g)
+#pragma unroll
+                        for (int m = 0; m < C::MT; ++m) asm volatile("" : "+v"(rv[g][m].x), "+v"(rv[g][m].y), "+v"(rv[g][m].z), "+v"(rv[g][m].w));
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int m = 0; m < W4_MT; ++m)
+            for (int m = 0; m < C::MT; ++m)
 #pragma unroll
                 for (int j = 0; j < NTL; ++j)
                     if constexpr (!(DBG & 1)) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[(DBG & 2) ? 0 : (st & 1)][j], afr[(DBG & 2) ? 0 : (st & 1)][m], acc[m][j], 0, 0, 0);  // D[cout][pixel]
-            if (st < W4_IN_ITERS && !(DBG & 8)) store_chunk(st, Rn, in_nxt);        // stage s+1 input -> other buffer
-            if (st == 0 && !(DBG & 32)) {                                           // weight slab of stage s+1 by LDS-DMA
-                const unsigned char* ws = wslab(sq1);
-                const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-                const unsigned w_nxt_lds = smem_lds + (unsigned)(buf_nxt - smem) + W4_IN_BYTES;
+            if (st >= 4) {
+                const int i = st - 4;
+                if (!(DBG & 8) && i < C::IN_ITERS) {
+                    store_chunk(i, R, in_nxt);                           // stage s+1 input -> other tile
+                    load_chunk(sq2, i, R);                              // stage s+2 input -> R.v[i]
+                }
+                if constexpr (!(DBG & 32)) {                            // slab s+2: 9 DMA issues over 5 k-steps
+                    const unsigned char* ws = wslab(sq2);
+                    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+                    // branch-free issue (a CFG merge here makes hipcc drain vmcnt): waves past the slab's end re-fetch a
+                    // chunk group another wave also fetches (same bytes, same destination)
+                    static_assert(C::W_CHUNKS % 256 == 0 && C::W_CHUNKS >= C::THREADS, "slab = whole 256-chunk groups");
 #pragma unroll
-                for (int i = 0; i < C::W_ITERS; ++i) {
-                    static_assert(C::W_CHUNKS % W4_THREADS == 0, "branch-free DMA issue: a CFG merge here makes hipcc drain vmcnt");
-                    const int cbase = i * W4_THREADS + wave_u * 64;
-                    w4_glds16(ws + (size_t)(cbase + lane) * 16, w_nxt_lds + cbase * 16);
+                    for (int d = 2 * i; d < 2 * i + 2 && d < C::W_ITERS; ++d) {
+                        int cbase = d * C::THREADS + wave_u * 64;
+                        if ((d + 1) * C::THREADS > C::W_CHUNKS) cbase = cbase >= C::W_CHUNKS ? cbase - 256 : cbase;
+                        w4_glds16(ws + (size_t)(cbase + lane) * 16, w_dst_lds + cbase * 16);
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // retire the s+2 prefetch and the weight DMA before the epilogue / barrier (in-order VMEM queue: see conv_rb.hip)
-#pragma unroll
-        for (int i = 0; i < W4_IN_ITERS; ++i) asm volatile("" : "+v"(Rf.v[i].x), "+v"(Rf.v[i].y), "+v"(Rf.v[i].z), "+v"(Rf.v[i].w));
         stamp(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(2);
     };
-    // ---- epilogue: NTL passes of 32 channels through buf[cur]; only READS the accumulators (the item loop below
-    // zeroes them unconditionally: with all 256 AGPRs holding acc, a conditional redefinition is a 256-register PHI
-    // that the allocator can only resolve by spilling accumulators to scratch).
-    auto epilogue = [&](auto par_tag) {
-        constexpr int PAR = decltype(par_tag)::value;
-        unsigned char* buf_cur = smem + PAR * C::BUF_STRIDE;
-        {
-            const W4Item it = sq0.it;
-            const int oy0 = it.ty * W4_TH, ox0 = it.tx * W4_TW, cout0 = it.nb * NT;
-            char* obase = reinterpret_cast<char*>(a.out) + (size_t)it.img * a.Hout * a.Wout * a.cout * 2;
-            const char* rbase = reinterpret_cast<const char*>(a.resid) + (size_t)it.img * a.Hout * a.Wout * a.cout * 2;
+    // ---- epilogue, straight from the accumulators (no LDS transpose, no workgroup barrier but the one for the GroupNorm
+    // partials).  Accumulator i of lane (r = pixel column, h) is cout j*32 + 8*(i>>2) + 4h + (i&3): a lane holds 4 consecutive
+    // couts (8 B packed) of chunk q = i>>2.  One v_permlane32_swap per register pairs chunk 2p of the h=0 lane with chunk
+    // 2p of the h=1 lane (and 2p+1 likewise), so every lane stores 16 contiguous bytes and a pixel's two lanes 32.
+    // It only READS acc: the item loop zeroes the accumulators unconditionally (a conditional redefinition of all 256
+    // AGPRs is a PHI the allocator can only resolve through scratch).
+    auto epilogue = [&]() {
+        const W4Item it = sq0.it;
+        int h_e = h;
+        asm volatile("" : "+v"(h_e));
+        const int cout0 = cout0_e;
+        char* obase = reinterpret_cast<char*>(a.out) + (size_t)it.img * a.Hout * a.Wout * a.cout * 2;
+        const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+        float ssum[NTL][2], qsum[NTL][2];
 #pragma unroll
-            for (int j = 0; j < NTL; ++j) {
-                // register-only instructions (v_accvgpr_read of the NEXT passes) may legally move across __syncthreads():
-                // pin every pass, or 256 accumulator copies are live at once and the allocator spills the hot loop's state
-                __builtin_amdgcn_sched_barrier(0);
-                int te = tid;
-                asm volatile("" : "+v"(te));
-                const int cc = te & 3;
-                uint4 rv[C::OUT_ITERS];
+        for (int g = 0; g < NTL * 2; ++g) {            // g = j*2 + p: chunks 2p, 2p+1 of the 32 couts j
+            const int j = g >> 1, pp = g & 1;
+            __builtin_amdgcn_sched_barrier(0);          // keep only one group's accumulator copies live
+            if (g + RD - 1 < NTL * 2) load_resid(g + RD - 1, rv[(g + RD - 1) % RD]);
+            const float4 b0 = *reinterpret_cast<const float4*>(bias_lds + cout0 + j * 32 + 16 * pp + 4 * h_e);
+            const float4 b1 = *reinterpret_cast<const float4*>(bias_lds + cout0 + j * 32 + 16 * pp + 8 + 4 * h_e);
+            float ts = 0.f, tq = 0.f;
+#pragma unroll
+            for (int m = 0; m < C::MT; ++m) {
+                const f32x16_t& c = acc[m][j];
+                unsigned x0 = w4_pack(c[8 * pp + 0] + b0.x, c[8 * pp + 1] + b0.y), x1 = w4_pack(c[8 * pp + 2] + b0.z, c[8 * pp + 3] + b0.w);
+                unsigned y0 = w4_pack(c[8 * pp + 4] + b1.x, c[8 * pp + 5] + b1.y), y1 = w4_pack(c[8 * pp + 6] + b1.z, c[8 * pp + 7] + b1.w);
+                asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x0), "+v"(y0));
+                asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x1), "+v"(y1));
+                unsigned w[4] = {x0, x1, y0, y1};
                 if constexpr (RESID) {
+                    const uint4 rr = rv[g % RD][m];
+                    const unsigned rw[4] = {rr.x, rr.y, rr.z, rr.w};
 #pragma unroll
-                    for (int k = 0; k < C::OUT_ITERS; ++k) {
-                        const int pix = (te + k * W4_THREADS) >> 2;
-                        const int oy = min(oy0 + (pix >> 5), a.Hout - 1), ox = min(ox0 + (pix & 31), a.Wout - 1);
-                        const unsigned off = ((unsigned)((oy * a.Wout + ox) * a.cout + cout0 + j * 32) << 1) + (unsigned)(cc * 16);
-                        rv[k] = *reinterpret_cast<const uint4*>(rbase + off);
-                    }
+                    for (int d = 0; d < 4; ++d) w[d] = w4_pack(w4_lo(w[d]) + w4_lo(rw[d]), w4_hi(w[d]) + w4_hi(rw[d]));
                 }
-                __syncthreads();          // previous pass drained / every wave done reading buf[cur] fragments
-                // accumulator i of lane (r = pixel column, h) is cout j*32 + 8*(i>>2) + 4h + (i&3)
-                int r_e = r, h_e = h;
-                asm volatile("" : "+v"(r_e), "+v"(h_e));
+                float s1 = 0.f, q1 = 0.f;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    __builtin_amdgcn_sched_barrier(0);      // at most 16 accumulator copies live at a time
-                    const float4 bv = *reinterpret_cast<const float4*>(bias_lds + cout0 + j * 32 + 8 * q + 4 * h_e);
-#pragma unroll
-                    for (int m = 0; m < W4_MT; ++m) {
-                        const int pix = (wave * W4_MT + m) * W4_TW + r_e;
-                        uint2 v;
-                        v.x = w4_pack(acc[m][j][4 * q + 0] + bv.x, acc[m][j][4 * q + 1] + bv.y);
-                        v.y = w4_pack(acc[m][j][4 * q + 2] + bv.z, acc[m][j][4 * q + 3] + bv.w);
-                        *reinterpret_cast<uint2*>(buf_cur + (pix * 4 + (q ^ (pix & 3))) * 16 + h_e * 8) = v;
-                    }
+                for (int d = 0; d < 4; ++d) {
+                    const bf16x2_t wv = __builtin_bit_cast(bf16x2_t, w[d]);
+                    s1 = __builtin_amdgcn_fdot2_f32_bf16(wv, ones, s1, false);
+                    q1 = __builtin_amdgcn_fdot2_f32_bf16(wv, wv, q1, false);
                 }
-                __syncthreads();
-                float sA = 0.f, qA = 0.f, sB = 0.f, qB = 0.f;
+                ts += inb[m] ? s1 : 0.f; tq += inb[m] ? q1 : 0.f;
+                if (inb[m] && (!(DBG & 4) || w[0] == 0x12345678u)) *reinterpret_cast<uint4*>(obase + offs[m] + (unsigned)(j * 64 + pp * 32)) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            ssum[j][pp] = ts; qsum[j][pp] = tq;
+        }
+        if (a.stats) {
+            // GroupNorm partials: group size G = 16 or 32 here (C >= 128), slot (j, p) = 16 couts => 1 or 2 slots per group
 #pragma unroll
-                for (int k = 0; k < C::OUT_ITERS; ++k) {
-                    const int pix = (te + k * W4_THREADS) >> 2;
-                    const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
-                    const bool inb = oy < a.Hout && ox < a.Wout;
-                    const uint4 o = reinterpret_cast<const uint4*>(buf_cur)[pix * 4 + (cc ^ (pix & 3))];
-                    const unsigned off = ((unsigned)((oy * a.Wout + ox) * a.cout + cout0 + j * 32) << 1) + (unsigned)(cc * 16);
-                    unsigned w[4] = {o.x, o.y, o.z, o.w};
-                    if constexpr (RESID) {
-                        const unsigned rw[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w};
+            for (int g = 0; g < NTL * 2; ++g) {
+                const float sv = w4_wave_sum(ssum[g >> 1][g & 1]), qv = w4_wave_sum(qsum[g >> 1][g & 1]);
+                if (lane == 0) { red[(wave * 8 + g) * 2 + 0] = sv; red[(wave * 8 + g) * 2 + 1] = qv; }
+            }
+            __syncthreads();
+            const int G = a.group_size, spg = G >> 4, ngl = NT / G;     // slots per group (1 or 2), groups in the item
+            if (tid < ngl) {
+                float sv = 0.f, qv = 0.f;
 #pragma unroll
-                        for (int d = 0; d < 4; ++d)
-                            w[d] = w4_pack(w4_lo(w[d]) + w4_lo(rw[d]), w4_hi(w[d]) + w4_hi(rw[d]));
-                    }
-                    {
-                        const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
-                        float ts0 = 0.f, tq0 = 0.f, ts1 = 0.f, tq1 = 0.f;
+                for (int w = 0; w < WAVES; ++w)
 #pragma unroll
-                        for (int d = 0; d < 4; ++d) {
-                            const bf16x2_t wv = __builtin_bit_cast(bf16x2_t, w[d]);
-                            if (d < 2) { ts0 = __builtin_amdgcn_fdot2_f32_bf16(wv, ones, ts0, false); tq0 = __builtin_amdgcn_fdot2_f32_bf16(wv, wv, tq0, false); }
-                            else { ts1 = __builtin_amdgcn_fdot2_f32_bf16(wv, ones, ts1, false); tq1 = __builtin_amdgcn_fdot2_f32_bf16(wv, wv, tq1, false); }
-                        }
-                        sA += inb ? ts0 : 0.f; qA += inb ? tq0 : 0.f; sB += inb ? ts1 : 0.f; qB += inb ? tq1 : 0.f;
-                    }
-                    if (inb) *reinterpret_cast<uint4*>(obase + off) = make_uint4(w[0], w[1], w[2], w[3]);
-                }
-                if (a.stats) {
-                    // GroupNorm partials of this 32-channel pass: group size G >= 16 here (C >= 128) => the pass covers
-                    // 32/G groups, each = 2 or 4 whole 16-B chunks; reduce per chunk, combine on a few lanes.
-                    sA = w4_group_sum(sA + sB); qA = w4_group_sum(qA + qB);     // per (wave, cc): sum over its pixels
-                    if (lane < 4) { red[(wave * 4 + lane) * 4 + 0] = sA; red[(wave * 4 + lane) * 4 + 1] = qA; }
-                    __syncthreads();
-                    const int G = a.group_size, cpg = G >> 3, ngl = 32 / G;       // chunks per group (2 or 4), groups in the pass
-                    if (tid < ngl) {
-                        float s = 0.f, q = 0.f;
-#pragma unroll
-                        for (int w = 0; w < 4; ++w)
-#pragma unroll
-                            for (int k = 0; k < 4; ++k)
-                                if (k < cpg) { s += red[(w * 4 + tid * cpg + k) * 4 + 0]; q += red[(w * 4 + tid * cpg + k) * 4 + 1]; }
-                        const int gg = (cout0 + j * 32) / G + tid;
-                        float* st = a.stats + (((size_t)it.img * tiles_per_img + it.tile) * 8 + gg) * 2;
-                        st[0] = s; st[1] = q;
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int k = 0; k < 2; ++k)
+                        if (k < spg) { sv += red[(w * 8 + tid * spg + k) * 2 + 0]; qv += red[(w * 8 + tid * spg + k) * 2 + 1]; }
+                const int gg = cout0 / G + tid;
+                float* st = a.stats + (((size_t)it.img * tiles_per_img + it.tile) * 8 + gg) * 2;
+                st[0] = sv; st[1] = qv;
             }
         }
     };
@@ -359,50 +389,51 @@ __global__ __launch_bounds__(W4_THREADS) void conv_w4_kernel(ConvArgs a) {
         __syncthreads();          // stage barrier: buf[nxt] complete, buf[cur] free
         stamp(5);
         sq0 = sq1; sq1 = sq2; sq2 = decode(min(s + 3, S - 1));
+        widx = widx == 2 ? 0 : widx + 1;
+        par ^= 1;
     };
 
-    // ---- prologue ---------------------------------------------------------------------------------------------
+    // ---- prologue: stage 0 input + slab -> LDS directly; slab of stage 1 by copy as well; R <- stage 1 input --------------
     {
         float* bl = reinterpret_cast<float*>(smem + C::MAIN_BYTES + C::RED_BYTES);
         if (tid < a.cout && tid < 256) bl[tid] = a.bias[tid];
-        load_stage(sq0, R0);
-        const uint4* ws = reinterpret_cast<const uint4*>(wslab(sq0));
-        uint4* wd = reinterpret_cast<uint4*>(smem + W4_IN_BYTES);
-        for (int i = tid; i < C::W_CHUNKS; i += W4_THREADS) wd[i] = ws[i];
+        load_stage(sq0, R);
+        const uint4* ws0 = reinterpret_cast<const uint4*>(wslab(sq0));
+        const uint4* ws1 = reinterpret_cast<const uint4*>(wslab(sq1));
+        uint4* wd = reinterpret_cast<uint4*>(smem + C::W_BASE);
+        for (int i = tid; i < C::W_CHUNKS; i += C::THREADS) { wd[i] = ws0[i]; wd[C::W_CHUNKS + i] = ws1[i]; }
         uint4* in0 = reinterpret_cast<uint4*>(smem);
 #pragma unroll
-        for (int i = 0; i < W4_IN_ITERS; ++i) store_chunk(i, R0, in0);
-        load_stage(sq1, R1);
+        for (int i = 0; i < C::IN_ITERS; ++i) store_chunk(i, R, in0);
+        load_stage(sq1, R);
     }
     __syncthreads();
     // nkc is even (Cin/16 with Cin >= 128), so an item starts on an even stage and ends on an odd one
     for (int k = 0; k < my_items; ++k) {
         zero_acc();
-        // steady-state stage pairs, then the item's last pair peeled with the epilogue: a conditional epilogue inside the
+        // steady-state stages, then the item's last stage peeled with the epilogue: a conditional epilogue inside the
         // loop makes the allocator split live ranges of in-flight prefetch registers mid-stage (vmcnt(0) + v_mov)
-        for (int kc = 0; kc + 2 < nkc; kc += 2) {
-            compute(std::integral_constant<int, 0>{});
-            finish(s); ++s;
-            compute(std::integral_constant<int, 1>{});
+        for (int kc = 0; kc + 1 < nkc; ++kc) {
+            compute(std::false_type{});
             finish(s); ++s;
         }
-        compute(std::integral_constant<int, 0>{});
-        finish(s); ++s;
-        compute(std::integral_constant<int, 1>{});
+        epi_prefetch();
+        compute(std::true_type{});
         stamp(3);
-        epilogue(std::integral_constant<int, 1>{});
+        epilogue();
         finish(s); ++s;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the workgroup's LDS is released
 }
 
-template <int NT, bool RESID, bool UPS, int DBG = 0>
+template <int NT, int WAVES, bool RESID, bool UPS, int DBG = 0>
 void launch_w4(const ConvArgs& a, hipStream_t stream) {
     const int items = a.tiles_x * a.tiles_y * a.nimg * a.nblocks;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int grid = items < cus ? items : cus;
-    hipLaunchKernelGGL((conv_w4_kernel<NT, RESID, UPS, DBG>), dim3(grid), dim3(W4_THREADS), 0, stream, a);
+    hipLaunchKernelGGL((conv_w4_kernel<NT, WAVES, RESID, UPS, DBG>), dim3(grid), dim3(WAVES * 64), 0, stream, a);
     IRE_HIP(hipGetLastError());
 }
 
@@ -413,16 +444,20 @@ void conv_w4_launch(bool resid, const ConvArgs& a, hipStream_t stream) {
 #ifdef IRE_W4_STAMPS
     static const int dbg = std::getenv("IRE_W4_DBG") ? std::atoi(std::getenv("IRE_W4_DBG")) : 0;
     switch (dbg) {
-        case 1: return launch_w4<128, false, false, 1>(a, stream);
-        case 2: return launch_w4<128, false, false, 2>(a, stream);
-        case 8: return launch_w4<128, false, false, 8>(a, stream);
-        case 32: return launch_w4<128, false, false, 32>(a, stream);
-        case 40: return launch_w4<128, false, false, 40>(a, stream);
-        case 42: return launch_w4<128, false, false, 42>(a, stream);
+        case 1: return launch_w4<128, 4, false, false, 1>(a, stream);
+        case 2: return launch_w4<128, 4, false, false, 2>(a, stream);
+        case 8: return launch_w4<128, 4, false, false, 8>(a, stream);
+        case 32: return launch_w4<128, 4, false, false, 32>(a, stream);
+        case 40: return launch_w4<128, 4, false, false, 40>(a, stream);
+        case 42: return launch_w4<128, 4, false, false, 42>(a, stream);
+        case 46: return launch_w4<128, 4, false, false, 46>(a, stream);
+        case 4: return launch_w4<128, 4, false, false, 4>(a, stream);
         default: break;
     }
 #endif
-    if (resid) launch_w4<128, true, false>(a, stream); else launch_w4<128, false, false>(a, stream);
+    static const int waves = std::getenv("IRE_W4_WAVES") ? std::atoi(std::getenv("IRE_W4_WAVES")) : 8;
+    if (waves == 4) { if (resid) launch_w4<128, 4, true, false>(a, stream); else launch_w4<128, 4, false, false>(a, stream); }
+    else            { if (resid) launch_w4<128, 8, true, false>(a, stream); else launch_w4<128, 8, false, false>(a, stream); }
 }
 
 }  // namespace ire
