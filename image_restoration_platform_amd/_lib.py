@@ -33,6 +33,9 @@ SYMBOLS = {
     "ire_classify_device": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ire_restore_device": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ire_fuse_device": (_i, [_vp, _vp, _i, _i, _i, ctypes.c_double, _vp, _vp, _vp]),
+    "ire_preprocess_plan": (_i, [_i, _i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "ire_preprocess": (_i, [_vp, _u8p, _i, _i, _i, _i, _u8p, _i, _i]),
+    "ire_preprocess_device": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "ire_submit": (_i, [_vp, _u8p, _i, _i, _i, ctypes.POINTER(_vp)]),
     "ire_poll": (_i, [_vp, _vp, _i, _u8p, _vp, ctypes.POINTER(IreTimings)]),
     "ire_debug_classifier_sums": (_i, [_vp, _i, _vp]),

@@ -23,6 +23,7 @@ SOURCES = [
      (["-DIRE_W4_TICKS"] if os.environ.get("IRE_RB_ABLATE") == "2" else [])),
     ("gn.hip", []),
     ("fusion.hip", []),
+    ("preprocess.hip", []),
     ("engine.cpp", []),
     ("api.cpp", []),
 ]

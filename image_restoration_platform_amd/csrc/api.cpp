@@ -224,6 +224,31 @@ int ire_fuse_device(ire_engine* e, const uint8_t* d_rgb_views, int k, int h, int
     });
 }
 
+int ire_preprocess_plan(int width, int height, int orientation, int max_dim, int* out_w, int* out_h, int* resized) {
+    return guarded([&] {
+        if (!out_w || !out_h) fail(IRE_ERR_INVALID_INPUT, "invalid arguments to ire_preprocess_plan");
+        preprocess_plan(width, height, orientation, max_dim, out_w, out_h, resized);
+    });
+}
+
+int ire_preprocess(ire_engine* e, const uint8_t* rgb, int h, int w, int orientation, int max_dim, uint8_t* out_rgb, int out_h,
+                   int out_w) {
+    return guarded([&] {
+        Engine& E = eng(e);
+        std::lock_guard<std::mutex> lk(E.mutex());
+        E.preprocess_host(rgb, h, w, orientation, max_dim, out_rgb, out_h, out_w);
+    });
+}
+
+int ire_preprocess_device(ire_engine* e, const uint8_t* d_rgb, int h, int w, int orientation, int max_dim, uint8_t* d_out_rgb,
+                          int out_h, int out_w, void* stream) {
+    return guarded([&] {
+        Engine& E = eng(e);
+        std::lock_guard<std::mutex> lk(E.mutex());
+        E.preprocess_device(d_rgb, h, w, orientation, max_dim, d_out_rgb, out_h, out_w, (hipStream_t)stream);
+    });
+}
+
 int ire_submit(ire_engine* e, const uint8_t* rgb, int h, int w, int is_jpeg, ire_job** job_out) {
     return guarded([&] {
         eng(e);

@@ -91,6 +91,11 @@ public:
     void fuse_host_impl(const uint8_t* rgb_views, int k, int h, int w, double noise_score, uint8_t* out_rgb,
                         int32_t* shifts_out, ire_timings* t);
 
+    // preprocess step in front of the path (preprocess.hip): EXIF orientation + fit-inside Lanczos-3
+    void preprocess_device(const uint8_t* d_rgb, int h, int w, int orientation, int max_dim, uint8_t* d_out, int out_h, int out_w,
+                           hipStream_t s);
+    void preprocess_host(const uint8_t* rgb, int h, int w, int orientation, int max_dim, uint8_t* out, int out_h, int out_w);
+
     void debug_sums(int n, uint64_t* out);
     void debug_capture(bool on) { capture_ = on; captured_.clear(); }
     bool debug_activation(const std::string& name, float* out, size_t* count);
@@ -154,6 +159,12 @@ private:
     uint8_t* d_fQ_ = nullptr;
     unsigned* d_fsad_ = nullptr;
     int* d_fmisc_ = nullptr;
+    // preprocess scratch (tap tables, intermediate of the horizontal pass, host-path staging)
+    size_t pp_tab_cap_ = 0, pp_mid_cap_ = 0, pp_in_cap_ = 0, pp_out_cap_ = 0;
+    int32_t* d_pp_tab_ = nullptr;
+    uint8_t* d_pp_mid_ = nullptr;
+    uint8_t* d_pp_in_ = nullptr;
+    uint8_t* d_pp_out_ = nullptr;
 
     // network
     Net net_;
@@ -177,5 +188,7 @@ private:
     int64_t prof_n_[FAM_COUNT] = {};
     void prof_collect();
 };
+
+void preprocess_plan(int width, int height, int orientation, int max_dim, int* out_w, int* out_h, int* resized);
 
 }  // namespace ire

@@ -112,6 +112,34 @@ class Engine:
                                        ctypes.byref(t)))
         return out, shifts
 
+    def preprocess_plan(self, width, height, orientation=1, max_dim=2048):
+        """-> (out_w, out_h, resized): size rule of imagePreprocess.js:12-22,46-55 (host arithmetic, no GPU work)."""
+        ow, oh, rs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        self._check(self._lib.ire_preprocess_plan(int(width), int(height), int(orientation), int(max_dim), ctypes.byref(ow),
+                                                  ctypes.byref(oh), ctypes.byref(rs)))
+        return ow.value, oh.value, bool(rs.value)
+
+    def preprocess(self, rgb, orientation=1, max_dim=2048):
+        """stored pixels [H,W,3] uint8 -> upright pixels fitted inside max_dim (EXIF orient + Lanczos-3), on the GPU."""
+        rgb = np.ascontiguousarray(rgb)
+        if rgb.dtype != np.uint8 or rgb.ndim != 3 or rgb.shape[2] != 3:
+            raise EngineError(1, "invalid input: expected [H,W,3] uint8")
+        h, w, _ = rgb.shape
+        ow, oh, _ = self.preprocess_plan(w, h, orientation, max_dim)
+        out = np.empty((oh, ow, 3), np.uint8)
+        self._check(self._lib.ire_preprocess(self._h, _ptr(rgb), h, w, int(orientation), int(max_dim), _ptr(out), oh, ow))
+        return out
+
+    def preprocess_tensor(self, rgb_u8, orientation=1, max_dim=2048, stream=None):
+        import torch
+        assert rgb_u8.is_cuda and rgb_u8.dtype == torch.uint8 and rgb_u8.is_contiguous() and rgb_u8.dim() == 3
+        h, w, _ = rgb_u8.shape
+        ow, oh, _ = self.preprocess_plan(w, h, orientation, max_dim)
+        out = torch.empty((oh, ow, 3), dtype=torch.uint8, device=rgb_u8.device)
+        self._check(self._lib.ire_preprocess_device(self._h, ctypes.c_void_p(rgb_u8.data_ptr()), h, w, int(orientation), int(max_dim),
+                                                    ctypes.c_void_p(out.data_ptr()), oh, ow, self._stream_ptr(stream)))
+        return out
+
     def submit(self, rgb, is_jpeg=True):
         rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
         h, w, _ = rgb.shape

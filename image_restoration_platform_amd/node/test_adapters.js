@@ -57,6 +57,21 @@ async function restoreLikeReference(classifier, restorer, imageBuffer) {
   out.restoredSha = require('crypto').createHash('sha256').update(Buffer.from(r.restoredImage, 'base64').slice(9)).digest('hex');
   const bad = await restoreLikeReference(classifier, restorer, Buffer.from('not an image'));
   out.bad = bad;
+  if (spec.worker) {
+    // the queue worker (restoration_worker.js) over the same two seams: one job through a RestoratorService-shaped object
+    const wk = require('./restoration_worker.js');
+    const updates = [];
+    const restorator = { restore: async (buf) => {
+      const e = await restoreLikeReference(classifier, restorer, buf);
+      return e.success ? Object.assign(e, { enhancedPrompt: 'p', timings: Object.assign({ prompt_ms: 0, total_ms: 1 }, e.timings) })
+                       : { success: false, error: { message: e.error.message, code: e.error.code, type: /invalid|unsupported/i.test(e.error.message) ? 'INVALID_INPUT' : 'UNKNOWN_ERROR' }, timings: e.timings, metadata: { failureStage: 'CLASSIFICATION' } };
+    } };
+    const processor = wk.createJobProcessor({ restorator, jobStore: { update: async (id, patch) => { updates.push(patch.status); } } });
+    const good = await processor({ id: 'w1', attemptsMade: 0, data: { userId: 'u', image: img.toString('base64') } });
+    let err = null;
+    try { await processor({ id: 'w2', attemptsMade: 0, data: { userId: 'u', image: Buffer.from('junk').toString('base64') } }); } catch (e) { err = { message: e.message, unrecoverable: !!e.unrecoverable, type: e.type }; }
+    out.worker = { good, err, updates };
+  }
   if (spec.fuse) {
     const views = spec.fuse.map((f) => fs.readFileSync(f));
     const fr = await restorer.restoreImage({ prompt: 'p', images: views });

@@ -3,6 +3,8 @@
 Extends the reference's stub (server-python/main.py:1-7: GET /health -> {"ok": true, "service": "python"})
 with the endpoints its docs sketch (image-restoration-platform.md:1076-1127):
   POST /restore   body = one encoded image (JPEG/PNG/WebP bytes), optional ?prompt=  -> RestoratorService envelope
+                  ?preprocess=1 first runs the upload through the preprocess step of imagePreprocess.js:24-91
+                  (auto-orient + fit inside 2048 on the GPU, JPEG q85 4:4:4) as the Node middleware does before queueing
   POST /fuse      JSON {"images": [base64, ...2..3], "prompt": "..."}                 -> {base64Image, metadata}
   GET  /health/ready                                                                 -> service + engine health
 The engine is created on first use; without a gfx950 device every compute endpoint answers 503 with the
@@ -58,7 +60,7 @@ def ready():
 
 
 @app.post("/restore")
-async def restore(request: Request, prompt: str = None):
+async def restore(request: Request, prompt: str = None, preprocess: int = 0):
     body = await request.body()
     if not body:
         return _problem(400, "Bad Request", "invalid request: empty body, expected encoded image bytes")
@@ -66,10 +68,22 @@ async def restore(request: Request, prompt: str = None):
         svc = get_service()
     except Exception as e:  # noqa: BLE001
         return _problem(503, "Service Unavailable", str(e))
+    operations = None
+    if preprocess:
+        from ..preprocess import PreprocessError, preprocess_image
+        try:
+            rec = preprocess_image(_state["engine"], body)
+        except PreprocessError as e:
+            return _problem(e.status, "Image Preprocessing Failed", str(e))
+        except EngineError as e:
+            return _problem(503 if e.status == 3 else 400 if e.status == 1 else 500, "Engine error", e.message)
+        body, operations = rec["buffer"], rec["operations"]
     result = svc.restore(body, user_prompt=prompt, user_context={"userId": request.headers.get("x-user-id")})
     if not result["success"]:
         code = {"INVALID_INPUT": 400, "SERVICE_UNAVAILABLE": 503, "TIMEOUT": 504}.get(result["error"]["type"], 500)
         return JSONResponse(status_code=code, content=result)
+    if operations is not None:
+        result["metadata"]["preprocessOperations"] = operations        # req.file.preprocessOperations, imagePreprocess.js:78
     return result
 
 

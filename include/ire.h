@@ -117,6 +117,18 @@ int ire_restore_device(ire_engine* e, const uint8_t* d_rgb, int n, int h, int w,
 int ire_fuse_device(ire_engine* e, const uint8_t* d_rgb_views, int k, int h, int w, double noise_score,
                     uint8_t* d_out_rgb, int32_t* d_shifts, void* stream);
 
+/* ---- preprocess step in front of the path (server-node/src/middleware/imagePreprocess.js:24-91) ---- */
+/* Pixel part of preprocessImage(): EXIF auto-orient (:43) and fit-inside-max_dim Lanczos-3 resize (:46-55); the JPEG
+ * q85 4:4:4 encode (:57-64) stays with the host codec.  width/height are the STORED dimensions (what sharp's
+ * metadata() reports, :40,:46), orientation the EXIF tag 1..8, max_dim 2048 in the reference (:4).
+ * ire_preprocess_plan is pure host arithmetic (no GPU): it returns the upright, fitted size. */
+int ire_preprocess_plan(int width, int height, int orientation, int max_dim, int* out_w, int* out_h, int* resized);
+/* rgb: h*w*3 stored pixels; out: out_h*out_w*3 as planned.  Integer two-pass resampler, bit-exact with oracle/preprocess.py. */
+int ire_preprocess(ire_engine* e, const uint8_t* rgb, int h, int w, int orientation, int max_dim,
+                   uint8_t* out_rgb, int out_h, int out_w);
+int ire_preprocess_device(ire_engine* e, const uint8_t* d_rgb, int h, int w, int orientation, int max_dim,
+                          uint8_t* d_out_rgb, int out_h, int out_w, void* stream);
+
 /* ---- async batcher (restoreBatch's in-flight promises) ---------------------------------- */
 typedef struct ire_job ire_job;
 /* Queue one h x w image for restoration; jobs of equal shape are coalesced into batches of up

@@ -53,7 +53,7 @@ def test_node_seams_match_python_host(engine, tmp_path):
         p = tmp_path / f"v{i}.raw"
         p.write_bytes(_raw(v))
         vf.append(str(p))
-    out = _run(tmp_path, {"weights": weights.ensure_default(0), "image": str(f), "fuse": vf})
+    out = _run(tmp_path, {"weights": weights.ensure_default(0), "image": str(f), "fuse": vf, "worker": True})
     assert out["engine"] is True and out["allEqual"] is True and out["success"] is True
     scores, _ = engine.classify(img, is_jpeg=True)
     from image_restoration_platform_amd.prompt_enhancer import KEYS
@@ -65,3 +65,41 @@ def test_node_seams_match_python_host(engine, tmp_path):
     assert out["metadata"]["providerRequestId"].startswith("ire-")
     assert out["bad"]["success"] is False and out["bad"]["error"]["code"] == "RESTORATION_FAILED"
     assert out["fusedLen"] == 9 + 64 * 64 * 3
+    wk = out["worker"]                                   # the BullMQ-style worker over the engine-backed seams
+    assert wk["good"]["status"] == "succeeded" and wk["good"]["providerRequestId"].startswith("ire-")
+    assert wk["err"]["unrecoverable"] is True and wk["err"]["type"] == "INVALID_INPUT"
+    assert wk["updates"] == ["running", "succeeded", "running"]
+
+
+def test_queue_worker_contract():
+    """restoration_worker.js against a miniature BullMQ Worker: queue defaults and back-off of jobQueue.js:4-9,37-45,
+    retry / DLQ / refund / job-record rules of design.md:820-884,912-933."""
+    r = subprocess.run(["node", os.path.join(NODE_DIR, "test_worker.js")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    o = json.loads(r.stdout.strip().splitlines()[-1])
+    assert o["defaults"] == {"queueName": "image-restoration-jobs", "attempts": 5, "backoffBaseMs": 1000, "backoffJitter": 0.3,
+                             "removeOnComplete": 100, "removeOnFail": 500, "deadLetterName": "image-restoration-dlq", "concurrency": 5}
+    assert o["envDefaults"]["queueName"] == "q2" and o["envDefaults"]["attempts"] == 7 and o["envDefaults"]["backoffBaseMs"] == 250
+    # base * 2^(attempt-1), +-30 % jitter, rounded; attempt 0 clamps to exponent 0
+    assert o["backoffMid"] == [1000, 2000, 4000, 8000] and o["backoffLo"] == 700 and o["backoffHi"] == 1300 and o["backoffZero"] == 1000
+    assert o["queueName"] == "image-restoration-jobs" and o["concurrency"] == 5
+    # success: job record carries the reference's timing keys and the engine's request id; no pixels in the return value
+    assert o["first"]["status"] == "succeeded" and set(o["first"]["timings"]) == {"classify_ms", "prompt_ms", "restore_ms", "total_ms"}
+    last = o["firstLog"]["updates"][-1]
+    assert last["status"] == "succeeded" and last["costUsd"] == 0 and last["signedResultUrl"].endswith("/j1") and last["prompt"] == "P"
+    assert o["firstLog"]["calls"][0]["ctx"]["traceparent"] == "00-aa-bb-01" and o["firstLog"]["calls"][0]["prompt"] == "fix"
+    assert o["firstLog"]["stored"] == [6] and o["firstLog"]["dlq"] == [] and o["firstLog"]["refunds"] == []
+    # retryable failures go back to queued, with the jittered-exponential delays, then succeed; gcs_ref goes through loadImage
+    assert [u["status"] for u in o["retryLog"]["updates"]] == ["running", "queued", "running", "queued", "running", "succeeded"]
+    assert o["retryDelays"] == [1000, 2000] and o["retryLog"]["calls"][0]["bytes"] == len("from:originals/u2/j2")
+    # attempts exhausted: 4 delays, one DLQ entry, one refund, failed record with the error code
+    assert o["exhausted"] is None and o["exhaustedDelays"] == [1000, 2000, 4000, 8000]
+    dlq = o["exhaustedLog"]["dlq"]
+    assert len(dlq) == 1 and dlq[0]["name"] == "failed-restoration" and dlq[0]["payload"]["originalJobId"] == "j3" and dlq[0]["payload"]["attempts"] == 5
+    assert o["exhaustedLog"]["refunds"] == [["u3", "j3", 1]]
+    assert o["exhaustedLog"]["updates"][-1]["status"] == "failed" and o["exhaustedLog"]["updates"][-1]["error"]["code"] == "ENGINE_X"
+    # INVALID_INPUT and an empty payload are terminal on the first attempt
+    assert o["invalidAttempts"] == 1 and [u["status"] for u in o["invalidLog"]["updates"]] == ["running", "failed"]
+    assert o["invalidLog"]["refunds"] == [["u4", "j4", 1]] and len(o["invalidLog"]["dlq"]) == 1
+    assert o["emptyAttempts"] == 1 and o["emptyLog"]["calls"] == [] and o["emptyLog"]["updates"][-1]["error"]["code"] == "INVALID_INPUT"
+    assert "Worker class" in o["needsWorkerClass"]

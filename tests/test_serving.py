@@ -39,6 +39,11 @@ def test_restore_and_fuse_endpoints():
     out = np.asarray(Image.open(io.BytesIO(base64.b64decode(j["restoredImage"]))))
     assert out.shape == (96, 120, 3)
     assert c.post("/restore", content=b"garbage").status_code == 400
+    # ?preprocess=1: the upload first takes the imagePreprocess.js path (orient + fit, here a no-resize case) on the GPU
+    r = c.post("/restore?preprocess=1", content=_jpeg(synth.image(3, 80, 112)))
+    assert r.status_code == 200, r.text
+    assert r.json()["metadata"]["preprocessOperations"] == ["auto_orient", "compress_jpeg_q85", "attach_sRGB_icc"]
+    assert c.post("/restore?preprocess=1", content=b"garbage").status_code == 422
     views = synth.fusion_views(64, 64)
     r = c.post("/fuse", json={"images": [base64.b64encode(_jpeg(v)).decode() for v in views]})
     assert r.status_code == 200 and r.json()["metadata"]["estimatedCostUsd"] == 0
