@@ -105,11 +105,19 @@ struct RbCfg {
 #ifndef IRE_RB_DEFER
 #define IRE_RB_DEFER 1
 #endif
-    static constexpr bool DEFER = WRES && (IRE_RB_DEFER != 0);
+    // DIRECT (default): the epilogue stores straight from the accumulators (v_permlane32_swap pairs the two k-half lanes of a
+    // pixel into 16-B stores): no LDS transpose, no epilogue barriers, a third of the instructions.  IRE_RB_DIRECT=0 keeps the
+    // LDS-transposed (and, at C = 32, deferred) epilogue for A/B runs.
+#ifndef IRE_RB_DIRECT
+#define IRE_RB_DIRECT 1
+#endif
+    static constexpr bool DIRECT = IRE_RB_DIRECT != 0;
+    static constexpr bool DEFER = WRES && (IRE_RB_DEFER != 0) && !DIRECT;
     static constexpr int OUT_TILE_BYTES = RB_TH * RB_TW * NT * 2;
     static constexpr int O_OFF = 2 * RB_IN_BYTES + W_BYTES;
     static constexpr int MAIN_BYTES = WRES ? 2 * RB_IN_BYTES + W_BYTES + OUT_TILE_BYTES : 2 * (RB_IN_BYTES + W_BYTES);
-    static constexpr int RED_BYTES = 8 * (NT / 8) * 4 * 4;
+    static constexpr int RED_HALF = 8 * (NT / 8) * 4 * 4;     // [8 waves][NT/8 chunks][sA,qA,sB,qB]
+    static constexpr int RED_BYTES = 2 * RED_HALF;             // two copies, alternating per item (DIRECT: no barrier before the write)
     static constexpr int COEF_BYTES = 2 * 256;              // two stages x 32 channels x (A,B) floats
     static constexpr int BIAS_BYTES = 256 * 4;              // the layer's whole bias vector (cout <= 256)
     static constexpr int LDS_BYTES = MAIN_BYTES + RED_BYTES + COEF_BYTES + BIAS_BYTES;
@@ -301,11 +309,13 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
     zero_acc();
 
     // pending GroupNorm partials of the previous item (finished after the stage barrier)
-    int st_img = -1, st_tile = 0, st_nb = 0;
-    float* red = reinterpret_cast<float*>(smem + C::MAIN_BYTES);   // [8 waves][NCC][4]
+    int st_img = -1, st_tile = 0, st_nb = 0, st_par = 0, red_par = 0;
+    float* red_base = reinterpret_cast<float*>(smem + C::MAIN_BYTES);   // 2 x [8 waves][NCC][4]
+    float* red = red_base;
     auto flush_stats = [&]() {
         if (st_img < 0) return;
         if (a.stats == nullptr) { st_img = -1; return; }
+        const float* red = red_base + st_par * (C::RED_HALF / 4);
         const int Gs = a.group_size, ngl = NT / Gs;
         if (tid < ngl) {
             float s = 0.f, q = 0.f;
@@ -430,6 +440,97 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         }
         st_img = it.img; st_tile = it.tile; st_nb = it.nb;
     };
+    // ---- direct epilogue (C::DIRECT) ---------------------------------------------------------------------------
+    // Accumulator i of lane (r = pixel column, h) is cout j*32 + 8*(i>>2) + 4h + (i&3).  For 16-cout group g = (j, p): the
+    // lane packs chunks 2p and 2p+1 (4 couts = 8 B each); one v_permlane32_swap per register hands chunk 2p's other half to
+    // the h = 0 lane and chunk 2p+1's to the h = 1 lane, so each lane owns ONE whole 16-B chunk cc = j*4 + 2p + h of its pixel.
+    // GroupNorm partials are reduced over the 32 lanes of a half (same chunk) and land in red[wave][cc] as before.
+    constexpr int NG = NTL * 2;
+    uint4 erv[NG][2];
+    unsigned eoffs[2];
+    bool einb[2];
+    // always_inline: a lambda hipcc declines to inline keeps every by-reference capture (acc, the kernel arguments) in scratch
+    auto epi_prefetch = [&](const RbItem& it) __attribute__((always_inline)) {
+        int r_e = r, h_e = h, w_e = wave;
+        asm volatile("" : "+v"(r_e), "+v"(h_e), "+v"(w_e));
+        const int oyb = it.ty * RB_TH + w_e * 2, ox = it.tx * RB_TW + r_e;
+        const bool colok = ox < a.Wout;
+        const int oxc = min(ox, a.Wout - 1);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int oy = oyb + m;
+            einb[m] = colok && oy < a.Hout;
+            eoffs[m] = ((unsigned)((min(oy, a.Hout - 1) * a.Wout + oxc) * a.cout + it.nb * NT) << 1) + (unsigned)(h_e * 16);
+        }
+        if constexpr (RESID && !(DBG & 4)) {
+            const char* rbase = reinterpret_cast<const char*>(a.resid) + (size_t)it.img * a.Hout * a.Wout * a.cout * 2;
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) erv[g][m] = *reinterpret_cast<const uint4*>(rbase + eoffs[m] + (unsigned)(g * 32));
+        }
+    };
+    auto direct_epilogue = [&](const RbItem& it) __attribute__((always_inline)) {
+        int h_e = h;
+        asm volatile("" : "+v"(h_e));
+        const int cout0 = it.nb * NT;
+        char* obase = reinterpret_cast<char*>(a.out) + (size_t)it.img * a.Hout * a.Wout * a.cout * 2;
+        const float* bias_lds = reinterpret_cast<const float*>(smem + C::MAIN_BYTES + C::RED_BYTES + C::COEF_BYTES);
+        const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+        float* redw = red_base + red_par * (C::RED_HALF / 4);
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const int g = j * 2 + pp;
+            const float4 b0 = *reinterpret_cast<const float4*>(bias_lds + cout0 + j * 32 + 16 * pp + 4 * h_e);
+            const float4 b1 = *reinterpret_cast<const float4*>(bias_lds + cout0 + j * 32 + 16 * pp + 8 + 4 * h_e);
+            float sA = 0.f, qA = 0.f, sB = 0.f, qB = 0.f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const f32x16_t& c = acc[m][j];
+                unsigned x0 = rb_pack(c[8 * pp + 0] + b0.x, c[8 * pp + 1] + b0.y), x1 = rb_pack(c[8 * pp + 2] + b0.z, c[8 * pp + 3] + b0.w);
+                unsigned y0 = rb_pack(c[8 * pp + 4] + b1.x, c[8 * pp + 5] + b1.y), y1 = rb_pack(c[8 * pp + 6] + b1.z, c[8 * pp + 7] + b1.w);
+                asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x0), "+v"(y0));
+                asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x1), "+v"(y1));
+                unsigned w[4] = {x0, x1, y0, y1};
+                if constexpr (RESID && !(DBG & 4)) {
+                    const uint4 rr = erv[g][m];
+                    const unsigned rw[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) w[d] = rb_pack(rb_lo(w[d]) + rb_lo(rw[d]), rb_hi(w[d]) + rb_hi(rw[d]));
+                }
+                float ts0 = 0.f, tq0 = 0.f, ts1 = 0.f, tq1 = 0.f;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const bf16x2_t wv = __builtin_bit_cast(bf16x2_t, w[d]);
+                    if (d < 2) { ts0 = __builtin_amdgcn_fdot2_f32_bf16(wv, ones, ts0, false); tq0 = __builtin_amdgcn_fdot2_f32_bf16(wv, wv, tq0, false); }
+                    else { ts1 = __builtin_amdgcn_fdot2_f32_bf16(wv, ones, ts1, false); tq1 = __builtin_amdgcn_fdot2_f32_bf16(wv, wv, tq1, false); }
+                }
+                sA += einb[m] ? ts0 : 0.f; qA += einb[m] ? tq0 : 0.f; sB += einb[m] ? ts1 : 0.f; qB += einb[m] ? tq1 : 0.f;
+                if (einb[m]) {
+                    if constexpr (DBG & 4) { if (w[0] == 0x12345678u) obase[eoffs[m]] = 1; }
+                    else *reinterpret_cast<uint4*>(obase + eoffs[m] + (unsigned)(g * 32)) = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
+            if (a.stats != nullptr) {        // sum over the 32 lanes of each half (= one chunk each), not across halves
+                sA = rb_swap16_add(rb_ror_add<8>(rb_ror_add<4>(rb_ror_add<2>(rb_ror_add<1>(sA)))));
+                qA = rb_swap16_add(rb_ror_add<8>(rb_ror_add<4>(rb_ror_add<2>(rb_ror_add<1>(qA)))));
+                sB = rb_swap16_add(rb_ror_add<8>(rb_ror_add<4>(rb_ror_add<2>(rb_ror_add<1>(sB)))));
+                qB = rb_swap16_add(rb_ror_add<8>(rb_ror_add<4>(rb_ror_add<2>(rb_ror_add<1>(qB)))));
+                if ((lane & 31) == 0) {
+                    float* d = redw + (wave * NCC + j * 4 + 2 * pp + h_e) * 4;
+                    d[0] = sA; d[1] = qA; d[2] = sB; d[3] = qB;
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) asm volatile("" : "=v"(acc[m][j]));     // dead until the next item
+        st_img = it.img; st_tile = it.tile; st_nb = it.nb; st_par = red_par;
+        red_par ^= 1;
+    };
     RbItem pend{0, 0, 0, 0, 0};      // deferred epilogue: the item parked in O
     bool pend_valid = false;
 
@@ -459,6 +560,9 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         uint4 drv[C::OUT_ITERS];                    // deferred epilogue: residual of the parked item
         DrainStats dst{0.f, 0.f, 0.f, 0.f};
         if constexpr (C::DEFER) drain_load_resid(pend, drv);
+        if constexpr (C::DIRECT) {
+            if constexpr (WRES) epi_prefetch(sq0.it);                       // nkc == 1: every stage ends an item
+        }
 
         if constexpr (!WRES) { if (sq0.kc == 0) zero_acc(); }   // WRES (nkc == 1): step 0 accumulates onto an inline 0   // new item (not in the epilogue: 64 dead registers there)
         // (4) 18 MFMA k-steps from the current buffer, the s+1 transform interleaved between groups
@@ -545,7 +649,12 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         stamp(s, 2);
         // (6) last k-chunk of the item: epilogue
         const int kc = sq0.kc;
-        if constexpr (C::DEFER) {
+        if constexpr (C::DIRECT) {
+            // (streamed weights: the residual rows are requested here, not a stage ahead -- per-lane state carried
+            // through a stage that only conditionally ends an item costs more registers than the kernel has)
+            if constexpr (WRES) direct_epilogue(sq0.it);
+            else if (kc == nkc - 1) { epi_prefetch(sq0.it); direct_epilogue(sq0.it); }
+        } else if constexpr (C::DEFER) {
             // every stage ends an item (nkc == 1).  The previous item's tile was drained inside the loop above;
             // park this item's tile in O for the next stage.
             drain_finish(pend, pend_valid, dst);
@@ -581,6 +690,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         // (7) stage barrier: buf[nxt] complete, buf[cur] (and red[]) free
         __syncthreads();
         stamp(s, 5);
+        if constexpr (C::DIRECT) flush_stats();                 // red[st_par] is complete; its next writer is two items away
         sq0 = sq1; sq1 = sq2; sq2 = decode(min(s + 3, S - 1));
     };
 
