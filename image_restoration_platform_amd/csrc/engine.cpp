@@ -58,6 +58,7 @@ Engine::Engine(const ire_config& cfg) {
     if (const char* v = std::getenv("IRE_ACT_SPLIT_MINC")) act_split_min_c_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_RB_PRIO")) prio_young_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_W4")) use_w4_ = std::atoi(v);
+    if (const char* v = std::getenv("IRE_UP_RB_MINC")) up_rb_min_c_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_RB_STAMPS")) {   // diagnostic: "<cout>[r]" = stamp the first such ResBlock conv
         stamps_cout_ = std::atoi(v);
         stamps_resid_ = std::strchr(v, 'r') != nullptr;
@@ -462,7 +463,7 @@ void Engine::launch_conv(Lane& L, const ConvW& cw, const void* in0, const void* 
     a.cout = (cw.kind == CONV_HEAD) ? 32 : cw.cout;
     a.tiles_x = ceil_div(Wout, 32);
     const bool rb = (cw.kind == CONV_RB1 || cw.kind == CONV_RB2);
-    const bool up_rb = (cw.kind == CONV_UP) && rb_tile_h_ == kRbTileH && cw.cout >= 64;   // 64->32 @full res: v1 is faster (measured)
+    const bool up_rb = (cw.kind == CONV_UP) && rb_tile_h_ == kRbTileH && cw.cout >= up_rb_min_c_;
     a.tiles_y = ceil_div(Hout, (rb || up_rb) ? rb_tile_h_ : conv_tile_h(cw.kind));
     if (up_rb) a.stats = nullptr;
     a.nimg = nimg; a.nblocks = cw.nblocks;

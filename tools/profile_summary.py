@@ -1,0 +1,77 @@
+"""Turn rocprofv3 outputs into the summaries committed under profiles/.
+
+  python tools/profile_summary.py stats  <kernel_stats.csv> <out.md> "<title>" ["<footer>"]
+  python tools/profile_summary.py traffic <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <steps>
+
+`traffic`: FETCH_SIZE and WRITE_SIZE come from two separate `rocprofv3 --pmc` passes of
+`python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile` (2 steps traced).  Units are KiB; on gfx950
+FETCH_SIZE reports half of the bytes of wide coalesced reads and is doubled (MI355X_MICROARCH.md, HBM / rocprofv3 section).
+The conv3x3 family = every 3x3 conv kernel the engine's profiler counts in that family (conv_rb, conv_w4, and the 3x3
+conv_mfma instantiations: TAPS == 9 with KC8 == 4, i.e. not the stem and not the 1x1 fuse).
+"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def stats(src, dst, title, footer=""):
+    rows = list(csv.DictReader(open(src)))
+    with open(dst, "w") as f:
+        f.write(f"# {title}\n\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
+        for r in rows:
+            f.write(f"| `{r['Name'][:112]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |\n")
+        if footer:
+            f.write("\n" + footer + "\n")
+
+
+def is_conv3x3(name):
+    if "conv_rb_kernel" in name or "conv_w4_kernel" in name:
+        return True
+    if "conv_mfma_kernel<4, 9," in name and not name.rstrip().endswith("true>(ire::ConvArgs)"):   # last arg = HEAD: its own family
+        return True
+    return False
+
+
+def _sum(path, counter):
+    per = defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = r["Kernel_Name"]
+        per[k][0] += float(r["Counter_Value"])
+        per[k][1] += 1
+    return per
+
+
+def traffic(fetch_csv, write_csv, dst, steps):
+    steps = int(steps)
+    fe, wr = _sum(fetch_csv, "FETCH_SIZE"), _sum(write_csv, "WRITE_SIZE")
+    out = {
+        "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile",
+        "unit_note": "counters are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); WRITE_SIZE as is",
+        "family": "conv3x3 (conv_rb_kernel + conv_w4_kernel, all instantiations, + the stride-2 conv_mfma_kernel instantiation)",
+        "per_kernel": {},
+    }
+    tot_f = tot_w = 0.0
+    launches = 0
+    for k in sorted(fe):
+        if not is_conv3x3(k):
+            continue
+        f = fe[k][0] * 1024.0 * 2.0
+        w = wr.get(k, [0.0, 0])[0] * 1024.0
+        n = fe[k][1]
+        tot_f += f
+        tot_w += w
+        launches += n
+        out["per_kernel"][k[k.find("conv_"):][:100]] = {"launches": n // steps, "fetch_MiB_corrected": round(f / n / 2 ** 20, 1), "write_MiB": round(w / n / 2 ** 20, 1)}
+    out["launches_per_step"] = launches // steps
+    out["fetch_bytes_per_launch_corrected"] = tot_f / launches
+    out["write_bytes_per_launch"] = tot_w / launches
+    out["hbm_bytes_per_launch"] = (tot_f + tot_w) / launches
+    json.dump(out, open(dst, "w"), indent=1)
+    print(json.dumps({k: out[k] for k in ("launches_per_step", "hbm_bytes_per_launch")}))
+
+
+if __name__ == "__main__":
+    {"stats": stats, "traffic": traffic}[sys.argv[1]](*sys.argv[2:])
