@@ -34,6 +34,7 @@ struct ConvArgs {
     int Hin, Win, Hout, Wout, cout;
     int tiles_x, tiles_y, nimg, nblocks;
     int group_size;              // cout / 8
+    int stat_slots;              // 0: stats[nimg][tiles][8][2] per tile; > 0 (= grid size): stats[nimg][slots][8][2], one entry per workgroup
     int prio_young;              // conv_rb: raise the issue priority of waves 4-7
     unsigned long long* stamps;  // diagnostic builds only (IRE_RB_ABLATE, DBG bit 16): s_memtime stamps, else null
 };
@@ -48,6 +49,9 @@ void conv_launch(ConvKind kind, const ConvArgs& a, hipStream_t stream);
 constexpr int kRbTileH = 16;
 // fused_act: apply y = silu(x*A+B) while staging (a.ab); otherwise the input is already activated.
 void conv_rb_launch(bool resid, bool fused_act, const ConvArgs& a, hipStream_t stream);
+// Workgroups conv_rb_launch will start for `a` if that instantiation accumulates GroupNorm partials per workgroup
+// (a.stat_slots must then be set to it), else 0 (per-tile partials).
+int conv_rb_stat_slots(bool fused_act, const ConvArgs& a);
 // One-wave-per-SIMD variant for C >= 128 ResBlock convs on a pre-activated input (conv_w4.hip):
 // a.nkc = Cin/16, a.nblocks = cout/128, a.w = slabs [nblock][kc16][tap*2 + c8][128][8], 16x32 tiles.
 void conv_w4_launch(bool resid, const ConvArgs& a, hipStream_t stream);

@@ -59,6 +59,7 @@ Engine::Engine(const ire_config& cfg) {
     if (const char* v = std::getenv("IRE_RB_PRIO")) prio_young_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_W4")) use_w4_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_UP_RB_MINC")) up_rb_min_c_ = std::atoi(v);
+    if (const char* v = std::getenv("IRE_SLOT_STATS")) slot_stats_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_RB_STAMPS")) {   // diagnostic: "<cout>[r]" = stamp the first such ResBlock conv
         stamps_cout_ = std::atoi(v);
         stamps_resid_ = std::strchr(v, 'r') != nullptr;
@@ -469,6 +470,7 @@ void Engine::launch_conv(Lane& L, const ConvW& cw, const void* in0, const void* 
     a.nimg = nimg; a.nblocks = cw.nblocks;
     a.group_size = std::max(1, a.cout / 8);
     a.stamps = nullptr;
+    a.stat_slots = 0;
     a.prio_young = prio_young_;
     if (stamps_dev_ && rb && cw.cout == stamps_cout_ && (cw.kind == CONV_RB2) == stamps_resid_ && !stamps_taken_) {
         a.stamps = stamps_dev_;
@@ -487,6 +489,11 @@ void Engine::launch_conv(Lane& L, const ConvW& cw, const void* in0, const void* 
     else if (cw.kind == CONV_HEAD) fam = FAM_HEAD;
     prof_begin(fam, L.stream, flops, bytes);
     const bool w4 = rb && rb_tile_h_ == kRbTileH && use_w4_ && ab == nullptr && cw.d_w4 != nullptr;
+    if (a.stats) L.stat_parts = a.tiles_x * a.tiles_y;
+    if (slot_stats_ && !w4 && !up_rb && rb && rb_tile_h_ == kRbTileH && a.stats) {
+        a.stat_slots = conv_rb_stat_slots(ab != nullptr, a);
+        if (a.stat_slots) L.stat_parts = a.stat_slots;
+    }
     if (w4) {
         a.w = cw.d_w4; a.nkc = cw.cin / 16; a.nblocks = cw.cout / 128;
         conv_w4_launch(cw.kind == CONV_RB2, a, L.stream);
@@ -499,7 +506,8 @@ void Engine::launch_conv(Lane& L, const ConvW& cw, const void* in0, const void* 
 
 void Engine::launch_gn(Lane& L, const GNW& g, int nimg, int Ht, int Wt, int ntiles, const float* d_film) {
     prof_begin(FAM_GN, L.stream, 0, 0);
-    gn_finalize_launch(L.stats, nimg, ntiles, g.C, Ht * Wt, g.d_gamma, g.d_beta, d_film, kFilmDim, kFilmOff[g.level],
+    (void)ntiles;   // the producer recorded how many partials per image it wrote
+    gn_finalize_launch(L.stats, nimg, L.stat_parts, g.C, Ht * Wt, g.d_gamma, g.d_beta, d_film, kFilmDim, kFilmOff[g.level],
                        L.ab, L.stream);
     prof_end(L.stream);
 }

@@ -56,6 +56,7 @@ struct Lane {
     unsigned short* skip[3] = {};
     unsigned short* actbuf[4] = {};   // activated copy of a ResBlock conv input (levels with C >= act_split_min_c)
     float* stats = nullptr;
+    int stat_parts = 0;              // partials per image the last stats-producing conv wrote (tiles, or workgroup slots)
     float2* ab = nullptr;
 };
 
@@ -131,6 +132,7 @@ private:
     uint32_t flags_ = 0;
     int use_w4_ = 1;              // C >= 128 ResBlock convs on conv_w4.hip (IRE_W4=0: conv_rb.hip; IRE_W4_WAVES=4|8)
     int up_rb_min_c_ = 32;        // `up` convs with cout >= this run on conv_rb.hip (IRE_UP_RB_MINC), the rest on the v1 kernel
+    int slot_stats_ = 0;          // IRE_SLOT_STATS=1: per-workgroup GroupNorm partials at C = 32 (+2 % throughput, gives up bit-identity across batch compositions)
     int prio_young_ = 0;          // static s_setprio for waves 4-7 of conv_rb (A/B'd: it only swaps which half waits)
     int act_split_min_c_ = 128;  // ResBlock convs with C >= this read a pre-activated tensor (gn_apply_silu)
     int rb_tile_h_ = kRbTileH;  // 16: persistent pipelined conv_rb.hip; 8: conv_mfma.hip (IRE_CONV_V1=1)
