@@ -576,14 +576,22 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
             if (C::SLOT && a.stat_slots > 0) {
                 sl[g][0] += sA; sl[g][1] += qA; sl[g][2] += sB; sl[g][3] += qB;
             } else if (a.stats != nullptr) {        // sum over the 32 lanes of each half (= one chunk each), not across halves
+                // the four chains advance one step at a time, side by side: each DPP then reads a value written three
+                // instructions earlier and needs no s_nop padding (a chain reduced on its own gets one per step)
                 if constexpr (NT >= 64) {      // cout >= 64 => groups of >= 8 channels: a chunk never splits into two groups
                     sA += sB; qA += qB; sB = 0.f; qB = 0.f;
+                    sA = rb_ror_add<1>(sA); qA = rb_ror_add<1>(qA);
+                    sA = rb_ror_add<2>(sA); qA = rb_ror_add<2>(qA);
+                    sA = rb_ror_add<4>(sA); qA = rb_ror_add<4>(qA);
+                    sA = rb_ror_add<8>(sA); qA = rb_ror_add<8>(qA);
+                    sA = rb_swap16_add(sA); qA = rb_swap16_add(qA);
                 } else {
-                    sB = rb_swap16_add(rb_ror_add<8>(rb_ror_add<4>(rb_ror_add<2>(rb_ror_add<1>(sB)))));
-                    qB = rb_swap16_add(rb_ror_add<8>(rb_ror_add<4>(rb_ror_add<2>(rb_ror_add<1>(qB)))));
+                    sA = rb_ror_add<1>(sA); qA = rb_ror_add<1>(qA); sB = rb_ror_add<1>(sB); qB = rb_ror_add<1>(qB);
+                    sA = rb_ror_add<2>(sA); qA = rb_ror_add<2>(qA); sB = rb_ror_add<2>(sB); qB = rb_ror_add<2>(qB);
+                    sA = rb_ror_add<4>(sA); qA = rb_ror_add<4>(qA); sB = rb_ror_add<4>(sB); qB = rb_ror_add<4>(qB);
+                    sA = rb_ror_add<8>(sA); qA = rb_ror_add<8>(qA); sB = rb_ror_add<8>(sB); qB = rb_ror_add<8>(qB);
+                    sA = rb_swap16_add(sA); qA = rb_swap16_add(qA); sB = rb_swap16_add(sB); qB = rb_swap16_add(qB);
                 }
-                sA = rb_swap16_add(rb_ror_add<8>(rb_ror_add<4>(rb_ror_add<2>(rb_ror_add<1>(sA)))));
-                qA = rb_swap16_add(rb_ror_add<8>(rb_ror_add<4>(rb_ror_add<2>(rb_ror_add<1>(qA)))));
                 if ((lane & 31) == 0) {
                     float* d = redw + (wave * NCC + j * 4 + 2 * pp + h_e) * 4;
                     d[0] = sA; d[1] = qA; d[2] = sB; d[3] = qB;
