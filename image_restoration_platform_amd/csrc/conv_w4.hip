@@ -364,10 +364,26 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
         }
         if (a.stats) {
             // GroupNorm partials: group size G = 16 or 32 here (C >= 128), slot (j, p) = 16 couts => 1 or 2 slots per group
+            // all 2*NG chains advance one step at a time, side by side: every DPP reads a value written >= 3 instructions
+            // earlier (no s_nop padding); then one 8-B LDS write per group
+            float rv16[NTL * 4];
 #pragma unroll
-            for (int g = 0; g < NTL * 2; ++g) {
-                const float sv = w4_wave_sum(ssum[g >> 1][g & 1]), qv = w4_wave_sum(qsum[g >> 1][g & 1]);
-                if (lane == 0) { red[(wave * 8 + g) * 2 + 0] = sv; red[(wave * 8 + g) * 2 + 1] = qv; }
+            for (int g = 0; g < NTL * 2; ++g) { rv16[2 * g] = ssum[g >> 1][g & 1]; rv16[2 * g + 1] = qsum[g >> 1][g & 1]; }
+#pragma unroll
+            for (int i = 0; i < NTL * 4; ++i) rv16[i] = w4_ror_add<1>(rv16[i]);
+#pragma unroll
+            for (int i = 0; i < NTL * 4; ++i) rv16[i] = w4_ror_add<2>(rv16[i]);
+#pragma unroll
+            for (int i = 0; i < NTL * 4; ++i) rv16[i] = w4_ror_add<4>(rv16[i]);
+#pragma unroll
+            for (int i = 0; i < NTL * 4; ++i) rv16[i] = w4_ror_add<8>(rv16[i]);
+#pragma unroll
+            for (int i = 0; i < NTL * 4; ++i) rv16[i] = w4_swap16_add(rv16[i]);
+#pragma unroll
+            for (int i = 0; i < NTL * 4; ++i) rv16[i] = w4_swap32_add(rv16[i]);
+            if (lane == 0) {
+#pragma unroll
+                for (int g = 0; g < NTL * 2; ++g) *reinterpret_cast<float2*>(red + (wave * 8 + g) * 2) = make_float2(rv16[2 * g], rv16[2 * g + 1]);
             }
             __syncthreads();
             const int G = a.group_size, spg = G >> 4, ngl = NT / G;     // slots per group (1 or 2), groups in the item
