@@ -64,21 +64,42 @@ __global__ __launch_bounds__(256) void fusion_sad_kernel(const uint8_t* __restri
     const int by = MODE == 0 ? 0 : 4 * coarse[v * 2], bx = MODE == 0 ? 0 : 4 * coarse[v * 2 + 1];
     const uint8_t* P0 = P;
     const uint8_t* Pv = P + (size_t)v * PH * PW;
+    // per-thread partial SAD of every candidate shift in registers (N = 81 / 49), accumulated over this thread's pixels;
+    // lanes are then summed by DPP row rotations + permlane swaps and each wave adds N values to LDS once.  Integer sums:
+    // any order gives the same result (bit-exact against oracle/fusion.py).
+    unsigned acc[N];
+#pragma unroll
+    for (int c = 0; c < N; ++c) acc[c] = 0u;
     for (int base = blockIdx.x * 256; base < nx * ny; base += gridDim.x * 256) {   // uniform trip count per block
         const int i = base + threadIdx.x;
         const bool valid = i < nx * ny;
         const int ii = valid ? i : 0;
         const int y = M + (ii / nx) * STEP, x = M + (ii % nx) * STEP;
         const int a = P0[(size_t)y * PW + x];
-        for (int dy = -R; dy <= R; ++dy)
+#pragma unroll
+        for (int dy = -R; dy <= R; ++dy) {
+            const int yy = min(max(y + by + dy, 0), PH - 1);
+            const uint8_t* row = Pv + (size_t)yy * PW;
+#pragma unroll
             for (int dx = -R; dx <= R; ++dx) {
-                const int yy = min(max(y + by + dy, 0), PH - 1), xx = min(max(x + bx + dx, 0), PW - 1);
-                const int d = a - (int)Pv[(size_t)yy * PW + xx];
-                unsigned val = valid ? (unsigned)(d < 0 ? -d : d) : 0u;
-                // wave-level sum first (integer: order independent), one LDS atomic per wave and shift
-                for (int off = 32; off >= 1; off >>= 1) val += __shfl_xor(val, off, 64);
-                if ((threadIdx.x & 63) == 0) atomicAdd(&s_sad[(dy + R) * (2 * R + 1) + dx + R], val);
+                const int xx = min(max(x + bx + dx, 0), PW - 1);
+                const int d = a - (int)row[xx];
+                acc[(dy + R) * (2 * R + 1) + dx + R] += valid ? (unsigned)(d < 0 ? -d : d) : 0u;
             }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+        unsigned val = acc[c];
+        val += (unsigned)__builtin_amdgcn_update_dpp(0, (int)val, 0x121, 0xf, 0xf, false);   // row_ror:1
+        val += (unsigned)__builtin_amdgcn_update_dpp(0, (int)val, 0x122, 0xf, 0xf, false);   // row_ror:2
+        val += (unsigned)__builtin_amdgcn_update_dpp(0, (int)val, 0x124, 0xf, 0xf, false);   // row_ror:4
+        val += (unsigned)__builtin_amdgcn_update_dpp(0, (int)val, 0x128, 0xf, 0xf, false);   // row_ror:8 -> row sums
+        acc[c] = val;
+    }
+    if ((threadIdx.x & 15) == 0) {            // one lane per 16-lane row
+#pragma unroll
+        for (int c = 0; c < N; ++c) atomicAdd(&s_sad[c], acc[c]);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < N; i += 256)
@@ -177,9 +198,9 @@ void Engine::fuse_launch(const uint8_t* d_views, int k, int h, int w, const unsi
     IRE_HIP(hipMemsetAsync(d_fsad_, 0, sizeof(unsigned) * 2 * (NC + NF), s));
     const int nq = k * (int)qpx;
     hipLaunchKernelGGL(fusion_luma_kernel, dim3(ceil_div(nq, 256)), dim3(256), 0, s, d_views, k, h, w, d_fL_, d_fQ_);
-    hipLaunchKernelGGL(fusion_sad_kernel<0>, dim3(64, k - 1), dim3(256), 0, s, d_fQ_, k, h / 4, w / 4, d_coarse, d_fsad_);
+    hipLaunchKernelGGL(fusion_sad_kernel<0>, dim3(128, k - 1), dim3(256), 0, s, d_fQ_, k, h / 4, w / 4, d_coarse, d_fsad_);
     hipLaunchKernelGGL(fusion_pick_kernel<0>, dim3(1), dim3(64), 0, s, d_fsad_, k, d_coarse, d_sh);
-    hipLaunchKernelGGL(fusion_sad_kernel<1>, dim3(256, k - 1), dim3(256), 0, s, d_fL_, k, h, w, d_coarse, d_fsad_ + 2 * NC);
+    hipLaunchKernelGGL(fusion_sad_kernel<1>, dim3(512, k - 1), dim3(256), 0, s, d_fL_, k, h, w, d_coarse, d_fsad_ + 2 * NC);
     hipLaunchKernelGGL(fusion_pick_kernel<1>, dim3(1), dim3(64), 0, s, d_fsad_ + 2 * NC, k, d_coarse, d_sh);
     hipLaunchKernelGGL(fusion_blend_kernel, dim3(ceil_div((int)px, 256)), dim3(256), 0, s, d_views, k, h, w, d_sh, d_wlut, d_out);
     IRE_HIP(hipGetLastError());
