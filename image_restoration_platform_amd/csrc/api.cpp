@@ -51,55 +51,145 @@ struct ire_engine {
 
 namespace ire {
 
+// Two-slot pipeline (host feeding is what limits scaling): pinned staging buffers, H2D on a copy-in stream,
+// classify + restore on the engine's main stream, D2H on a copy-out stream; while the GPU works on batch k the thread
+// gathers batch k+1 into the other slot and hands batch k-1's pixels back to its jobs.
+struct BatchSlot {
+    uint8_t *pin_in = nullptr, *pin_out = nullptr, *d_in = nullptr, *d_out = nullptr, *pin_jp = nullptr, *d_jp = nullptr;
+    double* pin_sc = nullptr;
+    size_t cap = 0;                       // bytes of each image buffer
+    hipEvent_t ev_in = nullptr, ev_c0 = nullptr, ev_c1 = nullptr, ev_out = nullptr;
+    std::vector<std::shared_ptr<Job>> jobs;
+    int h = 0, w = 0;
+    int status = IRE_OK;
+    std::string err;
+    bool busy = false;
+};
+
+static void slot_reserve(BatchSlot& S, size_t bytes, int max_batch) {
+    if (!S.ev_in) {
+        IRE_HIP(hipEventCreateWithFlags(&S.ev_in, hipEventDisableTiming));
+        IRE_HIP(hipEventCreate(&S.ev_c0));
+        IRE_HIP(hipEventCreate(&S.ev_c1));
+        IRE_HIP(hipEventCreateWithFlags(&S.ev_out, hipEventDisableTiming));
+        IRE_HIP(hipHostMalloc((void**)&S.pin_jp, (size_t)max_batch));
+        IRE_HIP(hipHostMalloc((void**)&S.pin_sc, sizeof(double) * 7 * (size_t)max_batch));
+        IRE_HIP(hipMalloc((void**)&S.d_jp, (size_t)max_batch));
+    }
+    if (bytes <= S.cap) return;
+    if (S.pin_in) { (void)hipHostFree(S.pin_in); (void)hipHostFree(S.pin_out); (void)hipFree(S.d_in); (void)hipFree(S.d_out); }
+    S.cap = 0;
+    IRE_HIP(hipHostMalloc((void**)&S.pin_in, bytes));
+    IRE_HIP(hipHostMalloc((void**)&S.pin_out, bytes));
+    IRE_HIP(hipMalloc((void**)&S.d_in, bytes));
+    IRE_HIP(hipMalloc((void**)&S.d_out, bytes));
+    S.cap = bytes;
+}
+
+static void slot_free(BatchSlot& S) {
+    if (S.pin_in) { (void)hipHostFree(S.pin_in); (void)hipHostFree(S.pin_out); (void)hipFree(S.d_in); (void)hipFree(S.d_out); }
+    if (S.ev_in) {
+        (void)hipEventDestroy(S.ev_in); (void)hipEventDestroy(S.ev_c0); (void)hipEventDestroy(S.ev_c1); (void)hipEventDestroy(S.ev_out);
+        (void)hipHostFree(S.pin_jp); (void)hipHostFree(S.pin_sc); (void)hipFree(S.d_jp);
+    }
+    S = BatchSlot{};
+}
+
+// wait for the slot's batch and hand results (or the error) to its jobs
+static void slot_finish(ire_engine* E, BatchSlot& S) {
+    if (!S.busy) return;
+    ire_timings t{};
+    if (S.status == IRE_OK) {
+        const hipError_t rc = hipEventSynchronize(S.ev_out);
+        if (rc != hipSuccess) { S.status = IRE_ERR_INTERNAL; S.err = std::string("internal: ") + hipGetErrorString(rc); }
+        else {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, S.ev_c0, S.ev_c1) == hipSuccess) { t.restore_ms = ms; t.total_ms = ms; }
+        }
+    }
+    const size_t ib = (size_t)S.h * S.w * 3;
+    const int n = (int)S.jobs.size();
+    for (int i = 0; i < n; ++i) {          // the pixel copies happen outside the queue lock
+        Job& j = *S.jobs[i];
+        if (S.status == IRE_OK) j.out.assign(S.pin_out + ib * i, S.pin_out + ib * (i + 1));
+    }
+    {
+        std::lock_guard<std::mutex> lk(E->qmu);
+        for (int i = 0; i < n; ++i) {
+            Job& j = *S.jobs[i];
+            if (S.status == IRE_OK) { std::memcpy(j.scores, S.pin_sc + 7 * i, sizeof(double) * 7); j.t = t; }
+            j.err = S.err;
+            j.in.clear(); j.in.shrink_to_fit();
+            j.status = S.status;
+        }
+    }
+    E->dcv.notify_all();
+    S.jobs.clear();
+    S.busy = false;
+}
+
 static void batcher_loop(ire_engine* E) {
     (void)hipSetDevice(E->device);
+    BatchSlot slots[2];
+    hipStream_t cs = nullptr, os = nullptr;
+    (void)hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+    (void)hipStreamCreateWithFlags(&os, hipStreamNonBlocking);
+    int p = 0;
     for (;;) {
-        std::vector<std::shared_ptr<Job>> batch;
+        BatchSlot& S = slots[p];
+        BatchSlot& prev = slots[p ^ 1];
         {
             std::unique_lock<std::mutex> lk(E->qmu);
+            // a batch is in flight and nothing new is queued: its jobs are waiting -- finish it before blocking on the queue
+            if (prev.busy && E->queue.empty() && !E->stop) { lk.unlock(); slot_finish(E, prev); lk.lock(); }
             E->qcv.wait(lk, [&] { return E->stop || !E->queue.empty(); });
-            if (E->stop && E->queue.empty()) return;
+            if (E->stop && E->queue.empty()) break;
             // small coalescing window: more submissions of the same shape usually follow at once
-            if ((int)E->queue.size() < E->eng->max_batch()) {
+            if ((int)E->queue.size() < E->eng->max_batch() && !prev.busy) {
                 E->qcv.wait_for(lk, std::chrono::microseconds(200),
                                 [&] { return E->stop || (int)E->queue.size() >= E->eng->max_batch(); });
             }
-            const int h = E->queue.front()->h, w = E->queue.front()->w;
-            for (auto it = E->queue.begin(); it != E->queue.end() && (int)batch.size() < E->eng->max_batch();) {
-                if ((*it)->h == h && (*it)->w == w) { batch.push_back(*it); it = E->queue.erase(it); }
+            S.h = E->queue.front()->h; S.w = E->queue.front()->w;
+            for (auto it = E->queue.begin(); it != E->queue.end() && (int)S.jobs.size() < E->eng->max_batch();) {
+                if ((*it)->h == S.h && (*it)->w == S.w) { S.jobs.push_back(*it); it = E->queue.erase(it); }
                 else ++it;
             }
         }
-        const int n = (int)batch.size(), h = batch[0]->h, w = batch[0]->w;
-        const size_t ib = (size_t)h * w * 3;
-        std::vector<uint8_t> in(ib * n), out(ib * n), jp(n);
-        std::vector<double> sc(7 * (size_t)n);
-        for (int i = 0; i < n; ++i) { std::memcpy(in.data() + ib * i, batch[i]->in.data(), ib); jp[i] = (uint8_t)batch[i]->is_jpeg; }
-        int status = IRE_OK;
-        std::string err;
-        ire_timings t{};
+        const int n = (int)S.jobs.size();
+        const size_t ib = (size_t)S.h * S.w * 3;
+        S.status = IRE_OK; S.err.clear(); S.busy = true;
         try {
-            std::lock_guard<std::mutex> lk(E->eng->mutex());
-            E->eng->classify_host(in.data(), n, h, w, 3 * w, jp.data(), sc.data(), nullptr);
-            E->eng->restore_host(in.data(), n, h, w, sc.data(), jp.data(), out.data(), &t);
-        } catch (const Error& e) { status = e.code; err = e.msg; }
-        catch (const std::exception& e) { status = IRE_ERR_INTERNAL; err = std::string("internal: ") + e.what(); }
-        {
-            std::lock_guard<std::mutex> lk(E->qmu);
-            for (int i = 0; i < n; ++i) {
-                Job& j = *batch[i];
-                if (status == IRE_OK) {
-                    j.out.assign(out.begin() + ib * i, out.begin() + ib * (i + 1));
-                    std::memcpy(j.scores, sc.data() + 7 * i, sizeof(double) * 7);
-                    j.t = t;
-                }
-                j.err = err;
-                j.status = status;
-                j.in.clear(); j.in.shrink_to_fit();
+            slot_reserve(S, ib * (size_t)E->eng->max_batch(), E->eng->max_batch());
+            for (int i = 0; i < n; ++i) { std::memcpy(S.pin_in + ib * i, S.jobs[i]->in.data(), ib); S.pin_jp[i] = (uint8_t)S.jobs[i]->is_jpeg; }
+            IRE_HIP(hipMemcpyAsync(S.d_in, S.pin_in, ib * n, hipMemcpyHostToDevice, cs));
+            IRE_HIP(hipMemcpyAsync(S.d_jp, S.pin_jp, (size_t)n, hipMemcpyHostToDevice, cs));
+            IRE_HIP(hipEventRecord(S.ev_in, cs));
+            {
+                std::lock_guard<std::mutex> lk(E->eng->mutex());
+                hipStream_t ms = E->eng->main_stream();
+                IRE_HIP(hipStreamWaitEvent(ms, S.ev_in, 0));
+                IRE_HIP(hipEventRecord(S.ev_c0, ms));
+                E->eng->restore_device(S.d_in, n, S.h, S.w, nullptr, S.d_jp, S.d_out, ms);       // classify inside
+                IRE_HIP(hipMemcpyAsync(S.pin_sc, E->eng->scores_device(), sizeof(double) * 7 * n, hipMemcpyDeviceToHost, ms));
+                IRE_HIP(hipEventRecord(S.ev_c1, ms));
             }
-        }
-        E->dcv.notify_all();
+            IRE_HIP(hipStreamWaitEvent(os, S.ev_c1, 0));
+            IRE_HIP(hipMemcpyAsync(S.pin_out, S.d_out, ib * n, hipMemcpyDeviceToHost, os));
+            IRE_HIP(hipEventRecord(S.ev_out, os));
+        } catch (const Error& e) { S.status = e.code; S.err = e.msg; }
+        catch (const std::exception& e) { S.status = IRE_ERR_INTERNAL; S.err = std::string("internal: ") + e.what(); }
+        slot_finish(E, prev);       // overlaps with the batch just launched
+        if (S.status != IRE_OK) slot_finish(E, S);
+        p ^= 1;
     }
+    slot_finish(E, slots[0]);
+    slot_finish(E, slots[1]);
+    (void)hipStreamSynchronize(cs);
+    (void)hipStreamSynchronize(os);
+    slot_free(slots[0]);
+    slot_free(slots[1]);
+    (void)hipStreamDestroy(cs);
+    (void)hipStreamDestroy(os);
 }
 
 template <typename F>

@@ -106,6 +106,8 @@ public:
     void profile_query(int fam, double* ms, int64_t* launches, double* flops, double* bytes);
 
     int max_batch() const { return max_batch_; }
+    hipStream_t main_stream() const { return main_stream_; }          // the stream of the host entry points and of the batcher's compute
+    const double* scores_device() const { return d_scores_; }       // [last n][7], valid after a classify on main_stream()
     std::mutex& mutex() { return mu_; }
 
 private:
