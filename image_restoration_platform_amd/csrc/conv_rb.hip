@@ -459,6 +459,10 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
     // the h = 0 lane and chunk 2p+1's to the h = 1 lane, so each lane owns ONE whole 16-B chunk cc = j*4 + 2p + h of its pixel.
     // GroupNorm partials are reduced over the 32 lanes of a half (same chunk) and land in red[wave][cc] as before.
     constexpr int NG = NTL * 2;
+#ifndef IRE_RB_NGP64
+#define IRE_RB_NGP64 0
+#endif
+    constexpr int NGP = (NT == 64 && FUSED_ACT) ? IRE_RB_NGP64 : NG;      // residual groups requested a stage ahead
     float sl[NG][4];                      // SLOT: per-lane running (sA, qA, sB, qB) of chunk j*4 + 2p + h
 #pragma unroll
     for (int g = 0; g < NG; ++g) sl[g][0] = sl[g][1] = sl[g][2] = sl[g][3] = 0.f;
@@ -519,7 +523,17 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         if constexpr (RESID && !(DBG & 4)) {
             const char* rbase = reinterpret_cast<const char*>(a.resid) + (size_t)it.img * a.Hout * a.Wout * a.cout * 2;
 #pragma unroll
-            for (int g = 0; g < NG; ++g)
+            for (int g = 0; g < NGP; ++g)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) erv[g][m] = *reinterpret_cast<const uint4*>(rbase + eoffs[m] + (unsigned)(g * 32));
+        }
+    };
+    // the groups not requested a stage ahead (register budget of the fused NT = 64 variant): requested when the epilogue starts
+    auto epi_fetch_rest = [&](const RbItem& it) __attribute__((always_inline)) {
+        if constexpr (RESID && !(DBG & 4) && NGP < NG) {
+            const char* rbase = reinterpret_cast<const char*>(a.resid) + (size_t)it.img * a.Hout * a.Wout * a.cout * 2;
+#pragma unroll
+            for (int g = NGP; g < NG; ++g)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) erv[g][m] = *reinterpret_cast<const uint4*>(rbase + eoffs[m] + (unsigned)(g * 32));
         }
@@ -528,6 +542,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         int h_e = h;
         asm volatile("" : "+v"(h_e));
         const int cout0 = it.nb * NT;
+        epi_fetch_rest(it);
         if constexpr (C::SLOT) {
             if (a.stats != nullptr && a.stat_slots > 0 && it.img != sl_img) {         // workgroup-uniform
                 if (sl_img >= 0) slot_flush(sl_img);
@@ -635,6 +650,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         if constexpr (C::DEFER) drain_load_resid(pend, drv);
         if constexpr (C::DIRECT) {
             if constexpr (WRES) epi_prefetch(sq0.it);                       // nkc == 1: every stage ends an item
+            else if constexpr (PAR == 1) { if (sq0.kc == nkc - 1) epi_prefetch(sq0.it); }   // nkc is even: items end on odd stages
         }
 
         if constexpr (!WRES) { if (sq0.kc == 0) zero_acc(); }   // WRES (nkc == 1): step 0 accumulates onto an inline 0   // new item (not in the epilogue: 64 dead registers there)
@@ -723,10 +739,8 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         // (6) last k-chunk of the item: epilogue
         const int kc = sq0.kc;
         if constexpr (C::DIRECT) {
-            // (streamed weights: the residual rows are requested here, not a stage ahead -- per-lane state carried
-            // through a stage that only conditionally ends an item costs more registers than the kernel has)
             if constexpr (WRES) direct_epilogue(sq0.it);
-            else if (kc == nkc - 1) { epi_prefetch(sq0.it); direct_epilogue(sq0.it); }
+            else if constexpr (PAR == 1) { if (kc == nkc - 1) direct_epilogue(sq0.it); }
         } else if constexpr (C::DEFER) {
             // every stage ends an item (nkc == 1).  The previous item's tile was drained inside the loop above;
             // park this item's tile in O for the next stage.
