@@ -136,7 +136,7 @@ private:
     int up_rb_min_c_ = 32;        // `up` convs with cout >= this run on conv_rb.hip (IRE_UP_RB_MINC), the rest on the v1 kernel
     int slot_stats_ = 0;          // IRE_SLOT_STATS=1: per-workgroup GroupNorm partials at C = 32 (+2 % throughput, gives up bit-identity across batch compositions)
     int prio_young_ = 0;          // static s_setprio for waves 4-7 of conv_rb (A/B'd: it only swaps which half waits)
-    int act_split_min_c_ = 128;  // ResBlock convs with C >= this read a pre-activated tensor (gn_apply_silu)
+    int act_split_min_c_ = 256;  // ResBlock convs with C >= this read a pre-activated tensor (gn_apply_silu); same-box A/B: 128 -> 747, 256 -> 763, 512 -> 754 img/s
     int rb_tile_h_ = kRbTileH;  // 16: persistent pipelined conv_rb.hip; 8: conv_mfma.hip (IRE_CONV_V1=1)
     std::mutex mu_;
     hipStream_t main_stream_ = nullptr;
