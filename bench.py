@@ -25,7 +25,7 @@ HBM_PEAK_GBS = 8000.0
 
 
 def cpu_baseline(size, budget_s=25.0):
-    """Oracle (CPU restatement, kind='port') on a bounded sample: one size x size image."""
+    """Oracle (CPU restatement, kind='port') on a bounded sample: three size x size images (about 15 s at 1024^2)."""
     import numpy as np
     import torch
     from image_restoration_platform_amd import synth, weights
@@ -33,16 +33,18 @@ def cpu_baseline(size, budget_s=25.0):
     from oracle import restorenet as onet
     cores = min(os.cpu_count() or 1, 16)   # a 1-GPU box's CPU share; more threads only oversubscribe
     torch.set_num_threads(cores)
-    img = synth.batch(1, size, size)
+    n = 3 if size <= 1024 else 1
+    img = synth.batch(n, size, size)
     w = weights.generate(0)
     t0 = time.perf_counter()
-    s, _ = oc.classify(img[0], True)
+    s = np.stack([oc.classify(img[i], True)[0] for i in range(n)])
     t1 = time.perf_counter()
-    onet.restore(img, s[None], w)
+    for i in range(n):          # one image at a time, as the reference's worker would (restorator.js:198-211)
+        onet.restore(img[i:i + 1], s[i:i + 1], w)
     t2 = time.perf_counter()
-    return {"value": 1.0 / (t2 - t0), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"1 image {size}x{size}: C classifier oracle (1 thread) {1e3 * (t1 - t0):.0f} ms + "
-                      f"PyTorch-CPU fp32 RestoreNet oracle ({cores} threads) {t2 - t1:.1f} s"}
+    return {"value": n / (t2 - t0), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} images {size}x{size}: C classifier oracle (1 thread) {1e3 * (t1 - t0) / n:.0f} ms/image + "
+                      f"PyTorch-CPU fp32 RestoreNet oracle ({cores} threads) {(t2 - t1) / n:.1f} s/image"}
 
 
 def aux_workload(args, eng, dev, rank, world, dist, torch, np, synth):

@@ -16,6 +16,9 @@ export function bindIre(libPath) {
     ire_fuse: ['int', [voidPtr, voidPtr, 'int', 'int', 'int', 'double', voidPtr, voidPtr, voidPtr]],
     ire_submit: ['int', [voidPtr, voidPtr, 'int', 'int', 'int', ref.refType(voidPtr)]],
     ire_poll: ['int', [voidPtr, voidPtr, 'int', voidPtr, voidPtr, voidPtr]],
+    // preprocess step in front of the path (imagePreprocess.js:24-91): size rule + orient / fit-inside resize on the GPU
+    ire_preprocess_plan: ['int', ['int', 'int', 'int', 'int', ref.refType('int'), ref.refType('int'), ref.refType('int')]],
+    ire_preprocess: ['int', [voidPtr, voidPtr, 'int', 'int', 'int', 'int', voidPtr, 'int', 'int']],
   });
 }
 // usage: lib.ire_classify.async(engine, rgb, 1, h, w, 3 * w, flags, scores, labels, cb)  (libuv pool, like sharp)
