@@ -154,12 +154,16 @@ def main():
         eng.profile_enable(1 if args.profile_all else 2)
     barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]    # per-step GPU time, no host sync inside
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        marks[i].record()
         step()
+    marks[args.steps].record()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     prof = None
     if not args.no_profile:
         eng.profile_enable(0)
@@ -176,6 +180,7 @@ def main():
             "value": world * args.steps * B / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "step_ms_p50": step_ms[len(step_ms) // 2], "step_ms_p95": step_ms[min(len(step_ms) - 1, int(0.95 * len(step_ms)))],
             "config": {"workload": "%dx%d RGB u8, batch %d per GPU: fused classifier scan + RestoreNet-v0 (43 convs, "
                                    "%.1f GFLOP/image), seeded random-init weights" % (S, S, B, (f3 + f1) / 1e9),
                        "global_batch": B * world, "parallelism": "per-image data parallel x%d, no collective" % world,
