@@ -20,7 +20,8 @@ SOURCES = [
     ("conv_rb.hip", (["-DIRE_RB_ABLATE"] if os.environ.get("IRE_RB_ABLATE") else []) +
      (["-DIRE_RB_DEFER=" + os.environ["IRE_RB_DEFER"]] if os.environ.get("IRE_RB_DEFER") else []) +
      (["-DIRE_RB_NGP64=" + os.environ["IRE_RB_NGP64"]] if os.environ.get("IRE_RB_NGP64") else []) +
-     (["-DIRE_RB_DIRECT=" + os.environ["IRE_RB_DIRECT"]] if os.environ.get("IRE_RB_DIRECT") else [])),
+     (["-DIRE_RB_DIRECT=" + os.environ["IRE_RB_DIRECT"]] if os.environ.get("IRE_RB_DIRECT") else []) +
+     (["-DIRE_RB_SLOT=" + os.environ["IRE_RB_SLOT"]] if os.environ.get("IRE_RB_SLOT") else [])),
     ("conv_w4.hip", (["-DIRE_W4_STAMPS"] if os.environ.get("IRE_RB_ABLATE") else []) +
      (["-DIRE_W4_TICKS"] if os.environ.get("IRE_RB_ABLATE") == "2" else [])),
     ("gn.hip", []),

@@ -113,13 +113,13 @@ struct RbCfg {
 #endif
     static constexpr bool DIRECT = IRE_RB_DIRECT != 0;
     static constexpr bool DEFER = WRES && (IRE_RB_DEFER != 0) && !DIRECT;
-    // SLOT (C = 32, direct epilogue; run-time opt-in through a.stat_slots > 0): GroupNorm partials stay in per-lane registers
+    // SLOT (C = 32, direct epilogue; build with IRE_RB_SLOT=1, then run-time opt-in through a.stat_slots > 0 / IRE_SLOT_STATS=1): GroupNorm partials stay in per-lane registers
     // across the workgroup's items and are reduced across lanes / waves only when the image changes (once per kernel at
     // bs 8): ~130 fewer instructions per item, -30 us per launch.  Opt-in because the fp32 summation order then depends on
     // how the batch's items were dealt to workgroups: results stay deterministic per call but are no longer bit-identical
     // across batch compositions (they are with the default per-tile partials + double-precision finalize).
 #ifndef IRE_RB_SLOT
-#define IRE_RB_SLOT 1
+#define IRE_RB_SLOT 0      // compiled out by default: the run-time dual path costs the default mode 0.8 % (same-box A/B 757 -> 763 img/s)
 #endif
     static constexpr bool SLOT = DIRECT && WRES && (IRE_RB_SLOT != 0);
     static constexpr int OUT_TILE_BYTES = RB_TH * RB_TW * NT * 2;
