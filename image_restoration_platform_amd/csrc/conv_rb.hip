@@ -327,15 +327,16 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
     float* red = red_base;
     auto flush_stats = [&]() {
         if (st_img < 0) return;
-        if (a.stats == nullptr) { st_img = -1; return; }
+        if (UPS || a.stats == nullptr) { st_img = -1; return; }
         const float* red = red_base + st_par * (C::RED_HALF / 4);
+        if (__builtin_amdgcn_readfirstlane(wave) != 0) { st_img = -1; return; }   // only wave 0 has work: spare the other waves the scalar ladder
         const int Gs = a.group_size, ngl = NT / Gs;
         if (tid < ngl) {
             float s = 0.f, q = 0.f;
             const int cpg = Gs >> 3;                       // 16-B chunks per group (0 when Gs == 4)
 #pragma unroll
             for (int w = 0; w < 8; ++w) {
-                if (Gs == 4) {                             // chunk = two groups: (cc, half)
+                if (NT == 32) {                            // cout = 32 => groups of 4: a chunk holds two groups (cc, half)
                     const float* d = red + (w * NCC + (tid >> 1)) * 4 + 2 * (tid & 1);
                     s += d[0]; q += d[1];
                 } else {
@@ -590,7 +591,8 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
             }
             if (C::SLOT && a.stat_slots > 0) {
                 sl[g][0] += sA; sl[g][1] += qA; sl[g][2] += sB; sl[g][3] += qB;
-            } else if (a.stats != nullptr) {        // sum over the 32 lanes of each half (= one chunk each), not across halves
+            } else if (!UPS) {        // ResBlock convs always feed a GroupNorm (a.stats != nullptr), `up` convs never do: no run-time branch
+                                      // sum over the 32 lanes of each half (= one chunk each), not across halves
                 // the four chains advance one step at a time, side by side: each DPP then reads a value written three
                 // instructions earlier and needs no s_nop padding (a chain reduced on its own gets one per step)
                 if constexpr (NT >= 64) {      // cout >= 64 => groups of >= 8 channels: a chunk never splits into two groups
@@ -870,6 +872,7 @@ int conv_rb_stat_slots(bool fused_act, const ConvArgs& a) {
 }
 
 void conv_rb_launch(bool resid, bool fused_act, const ConvArgs& a, hipStream_t stream) {
+    if (a.stats == nullptr) fail(IRE_ERR_INTERNAL, "internal: conv_rb_launch needs a GroupNorm partials buffer (ResBlock convs always feed a GroupNorm)");
 #ifdef IRE_RB_ABLATE
     static const int dbg = std::getenv("IRE_RB_DEBUG") ? std::atoi(std::getenv("IRE_RB_DEBUG")) : 0;
     switch (dbg) {
