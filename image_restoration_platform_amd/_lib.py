@@ -3,7 +3,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libire.so")
+LIB_PATH = os.environ.get("IRE_LIB") or os.path.join(HERE, "lib", "libire.so")   # IRE_LIB: A/B another build of the same ABI (tools/ab_bench.sh)
 
 IRE_OK, IRE_ERR_INVALID_INPUT, IRE_ERR_TIMEOUT, IRE_ERR_UNAVAILABLE, IRE_ERR_INTERNAL = range(5)
 

@@ -551,6 +551,8 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
             }
         }
         char* obase = reinterpret_cast<char*>(a.out) + (size_t)it.img * a.Hout * a.Wout * a.cout * 2;
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.Hout * a.Wout * a.cout * 2, 0x00020000);
+        (void)obase;
         const float* bias_lds = reinterpret_cast<const float*>(smem + C::MAIN_BYTES + C::RED_BYTES + C::COEF_BYTES);
         const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
         float* redw = red_base + red_par * (C::RED_HALF / 4);
@@ -584,9 +586,12 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
                     else { ts1 = __builtin_amdgcn_fdot2_f32_bf16(wv, ones, ts1, false); tq1 = __builtin_amdgcn_fdot2_f32_bf16(wv, wv, tq1, false); }
                 }
                 sA += einb[m] ? ts0 : 0.f; qA += einb[m] ? tq0 : 0.f; sB += einb[m] ? ts1 : 0.f; qB += einb[m] ? tq1 : 0.f;
-                if (einb[m]) {
-                    if constexpr (DBG & 4) { if (w[0] == 0x12345678u) obase[eoffs[m]] = 1; }
-                    else *reinterpret_cast<uint4*>(obase + eoffs[m] + (unsigned)(g * 32)) = make_uint4(w[0], w[1], w[2], w[3]);
+                if constexpr (DBG & 4) { if (einb[m] && w[0] == 0x12345678u) obase[eoffs[m]] = 1; }
+                else {
+                    // range-checked buffer store: lanes outside the image get an offset past num_records and the hardware
+                    // drops them -- no exec-mask branch per store
+                    const u32x4_t wv4 = {w[0], w[1], w[2], w[3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(wv4, orsrc, einb[m] ? eoffs[m] + (unsigned)(g * 32) : 0xffffffffu, 0, 0);
                 }
             }
             if (C::SLOT && a.stat_slots > 0) {

@@ -326,6 +326,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
         asm volatile("" : "+v"(h_e));
         const int cout0 = cout0_e;
         char* obase = reinterpret_cast<char*>(a.out) + (size_t)it.img * a.Hout * a.Wout * a.cout * 2;
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.Hout * a.Wout * a.cout * 2, 0x00020000);
         const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
         float ssum[NTL][2], qsum[NTL][2];
 #pragma unroll
@@ -358,7 +359,14 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
                     q1 = __builtin_amdgcn_fdot2_f32_bf16(wv, wv, q1, false);
                 }
                 ts += inb[m] ? s1 : 0.f; tq += inb[m] ? q1 : 0.f;
-                if (inb[m] && (!(DBG & 4) || w[0] == 0x12345678u)) *reinterpret_cast<uint4*>(obase + offs[m] + (unsigned)(j * 64 + pp * 32)) = make_uint4(w[0], w[1], w[2], w[3]);
+                const bool st_ok = inb[m] && (!(DBG & 4) || w[0] == 0x12345678u);
+                if constexpr (WAVES == 8) {
+                    // range-checked buffer store: out-of-image lanes get an offset past num_records and are dropped by the hardware
+                    const u32x4_t wv4 = {w[0], w[1], w[2], w[3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(wv4, orsrc, st_ok ? offs[m] + (unsigned)(j * 64 + pp * 32) : 0xffffffffu, 0, 0);
+                } else {          // 512-register form: no room for the resource descriptor's live range
+                    if (st_ok) *reinterpret_cast<uint4*>(obase + offs[m] + (unsigned)(j * 64 + pp * 32)) = make_uint4(w[0], w[1], w[2], w[3]);
+                }
             }
             ssum[j][pp] = ts; qsum[j][pp] = tq;
         }
