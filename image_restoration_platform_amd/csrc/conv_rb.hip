@@ -223,6 +223,9 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         const int oy1 = it.ty * RB_TH - 1, ox1 = it.tx * RB_TW - 1;
         // wave-uniform image base (SGPR pair) + 32-bit per-lane byte offset
         const char* base = reinterpret_cast<const char*>(src) + (size_t)it.img * a.Hin * a.Win * Cin * 2 + kc * 64;
+        // range-checked buffer loads: a halo pixel outside the image gets an offset past num_records and reads as zero --
+        // no coordinate clamping (4 min/max per chunk); the `ok` bit still gates the value AFTER the activation
+        const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, a.Hin * a.Win * Cin * 2 - kc * 64, 0x00020000);
         R.ok = 0;
         int t2 = tid;
         asm volatile("" : "+v"(t2));   // recompute the halo coordinates per stage: cheaper than 5 live registers
@@ -233,12 +236,14 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
             const int iy = oy1 + py, ix = ox1 + px;
             // UPS: the conv runs on the nearest-x2 upsampled grid (extent = output extent); source pixel = coord >> 1
             const int HV = UPS ? a.Hout : a.Hin, WV = UPS ? a.Wout : a.Win;
-            const int cy = min(max(iy, 0), HV - 1), cx = min(max(ix, 0), WV - 1);
-            const bool ok = iy == cy && ix == cx;   // slots past the tile (py >= 18) land in the LDS padding
-            const int sy = UPS ? (cy >> 1) : cy, sx = UPS ? (cx >> 1) : cx;
-            const unsigned off = ((unsigned)(sy * a.Win + sx) << (cin_shift + 1)) + (unsigned)(c8_fixed * 16);
+            const bool ok = (unsigned)iy < (unsigned)HV && (unsigned)ix < (unsigned)WV;   // slots past the tile (py >= 18) land in the LDS padding
+            const int sy = UPS ? (iy >> 1) : iy, sx = UPS ? (ix >> 1) : ix;
+            const unsigned off = ok ? ((unsigned)(sy * a.Win + sx) << (cin_shift + 1)) + (unsigned)(c8_fixed * 16) : 0xffffffffu;
             if constexpr (DBG & 8) R.v[i] = make_uint4(off, 0x3f803f80u, i, 0x3f803f80u);
-            else R.v[i] = *reinterpret_cast<const uint4*>(base + off);   // clamped: always in bounds
+            else {
+                const u32x4_t lv = __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, 0);
+                R.v[i] = make_uint4(lv.x, lv.y, lv.z, lv.w);
+            }
             R.ok |= ok ? (1u << i) : 0u;
         }
     };
@@ -461,7 +466,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
     // GroupNorm partials are reduced over the 32 lanes of a half (same chunk) and land in red[wave][cc] as before.
     constexpr int NG = NTL * 2;
 #ifndef IRE_RB_NGP64
-#define IRE_RB_NGP64 0
+#define IRE_RB_NGP64 4
 #endif
     constexpr int NGP = (NT == 64 && FUSED_ACT) ? IRE_RB_NGP64 : NG;      // residual groups requested a stage ahead
     float sl[NG][4];                      // SLOT: per-lane running (sA, qA, sB, qB) of chunk j*4 + 2p + h
