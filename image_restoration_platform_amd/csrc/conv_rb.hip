@@ -287,6 +287,8 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
             f32x2_t e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
             e = e + 1.0f;
             const f32x2_t rinv = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+            // (an inline-asm v_pk_mul_f32 here reads the v_rcp_f32 results before they are architecturally visible: hipcc pads
+            // transcendental -> VALU dependencies for its own instructions only)
             const f32x2_t sv = y * rinv;
             return rb_pack(sv.x, sv.y);
         } else {
@@ -572,8 +574,14 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const f32x16_t& c = acc[m][j];
-                unsigned x0 = rb_pack(c[8 * pp + 0] + b0.x, c[8 * pp + 1] + b0.y), x1 = rb_pack(c[8 * pp + 2] + b0.z, c[8 * pp + 3] + b0.w);
-                unsigned y0 = rb_pack(c[8 * pp + 4] + b1.x, c[8 * pp + 5] + b1.y), y1 = rb_pack(c[8 * pp + 6] + b1.z, c[8 * pp + 7] + b1.w);
+                unsigned x0, x1, y0, y1;
+                if constexpr (WRES) {      // bias already in the accumulators
+                    x0 = rb_pack(c[8 * pp + 0], c[8 * pp + 1]); x1 = rb_pack(c[8 * pp + 2], c[8 * pp + 3]);
+                    y0 = rb_pack(c[8 * pp + 4], c[8 * pp + 5]); y1 = rb_pack(c[8 * pp + 6], c[8 * pp + 7]);
+                } else {
+                    x0 = rb_pack(c[8 * pp + 0] + b0.x, c[8 * pp + 1] + b0.y); x1 = rb_pack(c[8 * pp + 2] + b0.z, c[8 * pp + 3] + b0.w);
+                    y0 = rb_pack(c[8 * pp + 4] + b1.x, c[8 * pp + 5] + b1.y); y1 = rb_pack(c[8 * pp + 6] + b1.z, c[8 * pp + 7] + b1.w);
+                }
                 asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x0), "+v"(y0));
                 asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x1), "+v"(y1));
                 unsigned w[4] = {x0, x1, y0, y1};
@@ -631,6 +639,9 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
             for (int j = 0; j < NTL; ++j) asm volatile("" : "=v"(acc[m][j]));     // dead until the next item
         if (!(C::SLOT && a.stat_slots > 0)) { st_img = it.img; st_tile = it.tile; st_nb = it.nb; st_par = red_par; red_par ^= 1; }
     };
+    // WRES + DIRECT (C = 32, one n-tile, nkc == 1): every item's accumulators START at the bias -- 16 registers for the whole
+    // kernel instead of 32 v_add_f32 per item in the epilogue.  Accumulator i of lane (r, h) is cout 8*(i>>2) + 4h + (i&3).
+    f32x16_t bias_acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     RbItem pend{0, 0, 0, 0, 0};      // deferred epilogue: the item parked in O
     bool pend_valid = false;
 
@@ -698,7 +709,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
                     for (int j = 0; j < NTL; ++j)
                     {
                         f32x16_t cin = acc[m][j];
-                        if constexpr (WRES) { if (st == 0) cin = f32x16_t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }
+                        if constexpr (WRES) { if (st == 0) cin = C::DIRECT ? bias_acc : f32x16_t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }
                         acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[st & 1][j], afr[st & 1][m], cin, 0, 0, 0);  // D[cout][pixel]
                     }
             } else if constexpr (!(DBG & 2)) {
@@ -819,6 +830,11 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         load_stage(sq1, R1);
     }
     __syncthreads();
+    if constexpr (WRES && C::DIRECT) {
+        const float* bl = reinterpret_cast<const float*>(smem + C::MAIN_BYTES + C::RED_BYTES + C::COEF_BYTES);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bias_acc[i] = bl[8 * (i >> 2) + 4 * h + (i & 3)];
+    }
 
     // Waves 4-7 are the later-dispatched partners on each SIMD and lose issue arbitration to waves 0-3 on every
     // stage (measured with s_memtime: their MFMA loop took 6600 vs 4600 cycles, the older half then idles at the
