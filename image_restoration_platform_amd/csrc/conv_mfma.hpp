@@ -52,6 +52,9 @@ void conv_rb_launch(bool resid, bool fused_act, const ConvArgs& a, hipStream_t s
 // Workgroups conv_rb_launch will start for `a` if that instantiation accumulates GroupNorm partials per workgroup
 // (a.stat_slots must then be set to it), else 0 (per-tile partials).
 int conv_rb_stat_slots(bool fused_act, const ConvArgs& a);
+// true when conv_rb.hip was built with the direct epilogue and therefore expects slab rows in permuted cout order
+// (row n of a 32-row tile = cout n with bits 2 and 3 swapped); conv_w4.hip always does.
+bool conv_rb_permuted_rows();
 // One-wave-per-SIMD variant for C >= 128 ResBlock convs on a pre-activated input (conv_w4.hip):
 // a.nkc = Cin/16, a.nblocks = cout/128, a.w = slabs [nblock][kc16][tap*2 + c8][128][8], 16x32 tiles.
 void conv_w4_launch(bool resid, const ConvArgs& a, hipStream_t stream);

@@ -462,10 +462,12 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         st_img = it.img; st_tile = it.tile; st_nb = it.nb;
     };
     // ---- direct epilogue (C::DIRECT) ---------------------------------------------------------------------------
-    // Accumulator i of lane (r = pixel column, h) is cout j*32 + 8*(i>>2) + 4h + (i&3).  For 16-cout group g = (j, p): the
-    // lane packs chunks 2p and 2p+1 (4 couts = 8 B each); one v_permlane32_swap per register hands chunk 2p's other half to
-    // the h = 0 lane and chunk 2p+1's to the h = 1 lane, so each lane owns ONE whole 16-B chunk cc = j*4 + 2p + h of its pixel.
-    // GroupNorm partials are reduced over the 32 lanes of a half (same chunk) and land in red[wave][cc] as before.
+    // MFMA row rho of lane (r = pixel column, h) is accumulator i with rho = 8*(i>>2) + 4h + (i&3).  The weight slab is stored
+    // with its rows permuted (bits 2 and 3 of rho swapped, engine.cpp::make_conv), which makes accumulator i the cout
+    // j*32 + 16*(i>>3) + 8h + (i&7): for 16-cout group g = (j, p) a lane owns ONE whole 16-B chunk cc = j*4 + 2p + h of its
+    // pixel in accumulators 8p..8p+7 -- packed and stored with no lane exchange (the natural row order needed one
+    // v_permlane32_swap + two wait states per register).  GroupNorm partials are reduced over the 32 lanes of a half
+    // (same chunk) and land in red[wave][cc].
     constexpr int NG = NTL * 2;
 #ifndef IRE_RB_NGP64
 #define IRE_RB_NGP64 4
@@ -568,8 +570,10 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
             const int g = j * 2 + pp;
-            const float4 b0 = *reinterpret_cast<const float4*>(bias_lds + cout0 + j * 32 + 16 * pp + 4 * h_e);
-            const float4 b1 = *reinterpret_cast<const float4*>(bias_lds + cout0 + j * 32 + 16 * pp + 8 + 4 * h_e);
+            // permuted slab rows (engine.cpp::make_conv): accumulators 8pp .. 8pp+7 of lane-half h are the 8 CONTIGUOUS couts
+            // j*32 + 16pp + 8h + (0..7) = 16-B chunk cc = j*4 + 2pp + h of the pixel: pack and store, no lane exchange
+            const float4 b0 = *reinterpret_cast<const float4*>(bias_lds + cout0 + j * 32 + 16 * pp + 8 * h_e);
+            const float4 b1 = *reinterpret_cast<const float4*>(bias_lds + cout0 + j * 32 + 16 * pp + 8 * h_e + 4);
             float sA = 0.f, qA = 0.f, sB = 0.f, qB = 0.f;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -582,8 +586,6 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
                     x0 = rb_pack(c[8 * pp + 0] + b0.x, c[8 * pp + 1] + b0.y); x1 = rb_pack(c[8 * pp + 2] + b0.z, c[8 * pp + 3] + b0.w);
                     y0 = rb_pack(c[8 * pp + 4] + b1.x, c[8 * pp + 5] + b1.y); y1 = rb_pack(c[8 * pp + 6] + b1.z, c[8 * pp + 7] + b1.w);
                 }
-                asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x0), "+v"(y0));
-                asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x1), "+v"(y1));
                 unsigned w[4] = {x0, x1, y0, y1};
                 if constexpr (RESID && !(DBG & 4)) {
                     const uint4 rr = erv[g][m];
@@ -640,7 +642,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         if (!(C::SLOT && a.stat_slots > 0)) { st_img = it.img; st_tile = it.tile; st_nb = it.nb; st_par = red_par; red_par ^= 1; }
     };
     // WRES + DIRECT (C = 32, one n-tile, nkc == 1): every item's accumulators START at the bias -- 16 registers for the whole
-    // kernel instead of 32 v_add_f32 per item in the epilogue.  Accumulator i of lane (r, h) is cout 8*(i>>2) + 4h + (i&3).
+    // kernel instead of 32 v_add_f32 per item in the epilogue.  Accumulator i of lane (r, h) is cout 16*(i>>3) + 8h + (i&7).
     f32x16_t bias_acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     RbItem pend{0, 0, 0, 0, 0};      // deferred epilogue: the item parked in O
     bool pend_valid = false;
@@ -833,7 +835,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
     if constexpr (WRES && C::DIRECT) {
         const float* bl = reinterpret_cast<const float*>(smem + C::MAIN_BYTES + C::RED_BYTES + C::COEF_BYTES);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) bias_acc[i] = bl[8 * (i >> 2) + 4 * h + (i & 3)];
+        for (int i = 0; i < 16; ++i) bias_acc[i] = bl[16 * (i >> 3) + 8 * h + (i & 7)];     // permuted slab rows
     }
 
     // Waves 4-7 are the later-dispatched partners on each SIMD and lose issue arbitration to waves 0-3 on every
@@ -896,6 +898,8 @@ int conv_rb_stat_slots(bool fused_act, const ConvArgs& a) {
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     return items < cus ? items : cus;
 }
+
+bool conv_rb_permuted_rows() { return RbCfg<64, false, false, true>::DIRECT; }
 
 void conv_rb_launch(bool resid, bool fused_act, const ConvArgs& a, hipStream_t stream) {
     if (a.stats == nullptr) fail(IRE_ERR_INTERNAL, "internal: conv_rb_launch needs a GroupNorm partials buffer (ResBlock convs always feed a GroupNorm)");

@@ -315,9 +315,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
         stamp(2);
     };
     // ---- epilogue, straight from the accumulators (no LDS transpose, no workgroup barrier but the one for the GroupNorm
-    // partials).  Accumulator i of lane (r = pixel column, h) is cout j*32 + 8*(i>>2) + 4h + (i&3): a lane holds 4 consecutive
-    // couts (8 B packed) of chunk q = i>>2.  One v_permlane32_swap per register pairs chunk 2p of the h=0 lane with chunk
-    // 2p of the h=1 lane (and 2p+1 likewise), so every lane stores 16 contiguous bytes and a pixel's two lanes 32.
+    // partials).  The slab rows are permuted (bits 2 and 3 of the MFMA row swapped, engine.cpp::make_conv), so accumulator i
+    // of lane (r = pixel column, h) is cout j*32 + 16*(i>>3) + 8h + (i&7): 8 contiguous couts per half tile = one 16-B
+    // store per lane, a pixel's two lanes 32 contiguous bytes, no lane exchange.
     // It only READS acc: the item loop zeroes the accumulators unconditionally (a conditional redefinition of all 256
     // AGPRs is a PHI the allocator can only resolve through scratch).
     auto epilogue = [&]() {
@@ -334,16 +334,15 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
             const int j = g >> 1, pp = g & 1;
             __builtin_amdgcn_sched_barrier(0);          // keep only one group's accumulator copies live
             if (g + RD - 1 < NTL * 2) load_resid(g + RD - 1, rv[(g + RD - 1) % RD]);
-            const float4 b0 = *reinterpret_cast<const float4*>(bias_lds + cout0 + j * 32 + 16 * pp + 4 * h_e);
-            const float4 b1 = *reinterpret_cast<const float4*>(bias_lds + cout0 + j * 32 + 16 * pp + 8 + 4 * h_e);
+            // permuted slab rows (engine.cpp::make_conv): accumulators 8pp .. 8pp+7 are the 8 contiguous couts j*32 + 16pp + 8h + (0..7)
+            const float4 b0 = *reinterpret_cast<const float4*>(bias_lds + cout0 + j * 32 + 16 * pp + 8 * h_e);
+            const float4 b1 = *reinterpret_cast<const float4*>(bias_lds + cout0 + j * 32 + 16 * pp + 8 * h_e + 4);
             float ts = 0.f, tq = 0.f;
 #pragma unroll
             for (int m = 0; m < C::MT; ++m) {
                 const f32x16_t& c = acc[m][j];
-                unsigned x0 = w4_pack(c[8 * pp + 0] + b0.x, c[8 * pp + 1] + b0.y), x1 = w4_pack(c[8 * pp + 2] + b0.z, c[8 * pp + 3] + b0.w);
-                unsigned y0 = w4_pack(c[8 * pp + 4] + b1.x, c[8 * pp + 5] + b1.y), y1 = w4_pack(c[8 * pp + 6] + b1.z, c[8 * pp + 7] + b1.w);
-                asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x0), "+v"(y0));
-                asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x1), "+v"(y1));
+                const unsigned x0 = w4_pack(c[8 * pp + 0] + b0.x, c[8 * pp + 1] + b0.y), x1 = w4_pack(c[8 * pp + 2] + b0.z, c[8 * pp + 3] + b0.w);
+                const unsigned y0 = w4_pack(c[8 * pp + 4] + b1.x, c[8 * pp + 5] + b1.y), y1 = w4_pack(c[8 * pp + 6] + b1.z, c[8 * pp + 7] + b1.w);
                 unsigned w[4] = {x0, x1, y0, y1};
                 if constexpr (RESID) {
                     const uint4 rr = rv[g % RD][m];

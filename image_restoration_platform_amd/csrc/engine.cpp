@@ -186,6 +186,20 @@ ConvW Engine::make_conv(ConvKind kind, const std::string& wname, const std::stri
     c.d_w = (unsigned short*)dalloc(arr.size() * 2);
     net_.allocs.push_back(c.d_w);
     IRE_HIP(hipMemcpy(c.d_w, arr.data(), arr.size() * 2, hipMemcpyHostToDevice));
+    // conv_rb.hip / conv_w4.hip (direct epilogue): slab row n of a 32-row MFMA tile carries cout perm(n) = n with bits 2 and 3
+    // swapped, so that the 16 accumulators of a lane-half are two runs of 8 CONTIGUOUS couts (one 16-B store each, no
+    // v_permlane32_swap pairing).  The v1 kernel keeps the natural order (c.d_w).
+    auto perm = [](int n) { return (n & ~12) | ((n & 4) << 1) | ((n & 8) >> 1); };
+    if ((kind == CONV_RB1 || kind == CONV_RB2 || kind == CONV_UP) && conv_rb_permuted_rows()) {
+        std::vector<unsigned short> arrp(arr.size(), 0);
+        const size_t rows = arr.size() / ((size_t)c.nt * 8);
+        for (size_t rr = 0; rr < rows; ++rr)
+            for (int n = 0; n < c.nt; ++n)
+                std::memcpy(&arrp[(rr * c.nt + n) * 8], &arr[(rr * c.nt + perm(n)) * 8], 16);
+        c.d_wp = (unsigned short*)dalloc(arrp.size() * 2);
+        net_.allocs.push_back(c.d_wp);
+        IRE_HIP(hipMemcpy(c.d_wp, arrp.data(), arrp.size() * 2, hipMemcpyHostToDevice));
+    }
     if ((kind == CONV_RB1 || kind == CONV_RB2) && cout >= 128 && cin % 16 == 0 && cout % 128 == 0) {
         // conv_w4.hip slabs: [nblock (128 couts)][kc16][kk = tap*2 + c8][128][8]
         const int nb4 = cout / 128, nk4 = cin / 16;
@@ -196,7 +210,7 @@ ConvW Engine::make_conv(ConvKind kind, const std::string& wname, const std::stri
                     const int tap = kk >> 1, c8 = kk & 1;
                     for (int n = 0; n < 128; ++n)
                         for (int e = 0; e < 8; ++e) {
-                            const int co = nb * 128 + n, ci = kc * 16 + c8 * 8 + e;
+                            const int co = nb * 128 + perm(n), ci = kc * 16 + c8 * 8 + e;       // permuted rows, as c.d_wp
                             arr4[((((size_t)nb * nk4 + kc) * 18 + kk) * 128 + n) * 8 + e] = f32_to_bf16(W[((size_t)co * cin + ci) * 9 + tap]);
                         }
                 }
@@ -497,8 +511,8 @@ void Engine::launch_conv(Lane& L, const ConvW& cw, const void* in0, const void* 
     if (w4) {
         a.w = cw.d_w4; a.nkc = cw.cin / 16; a.nblocks = cw.cout / 128;
         conv_w4_launch(cw.kind == CONV_RB2, a, L.stream);
-    } else if (up_rb) conv_up_launch(a, L.stream);
-    else if (rb && rb_tile_h_ == kRbTileH) conv_rb_launch(cw.kind == CONV_RB2, /*fused_act=*/ab != nullptr, a, L.stream);
+    } else if (up_rb) { if (cw.d_wp) a.w = cw.d_wp; conv_up_launch(a, L.stream); }
+    else if (rb && rb_tile_h_ == kRbTileH) { if (cw.d_wp) a.w = cw.d_wp; conv_rb_launch(cw.kind == CONV_RB2, /*fused_act=*/ab != nullptr, a, L.stream); }
     else conv_launch(cw.kind, a, L.stream);
     prof_end(L.stream);
     if (capture_ && cap_name && out) capture(cap_name, out, (size_t)nimg * Hout * Wout * cw.cout, L.stream);

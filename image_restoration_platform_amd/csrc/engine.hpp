@@ -26,6 +26,7 @@ struct ConvW {
     int cin0 = 0, cin1 = 0;      // channels per pixel of the two sources
     int nt = 0, nblocks = 0, nkc = 0, kc_split = 0;
     unsigned short* d_w = nullptr;
+    unsigned short* d_wp = nullptr;   // slabs with permuted cout rows for conv_rb.hip's direct epilogue
     unsigned short* d_w4 = nullptr;  // second arrangement for conv_w4.hip (C >= 128 ResBlock convs): 16-channel stages, 128-cout blocks
     float* d_bias = nullptr;
 };
