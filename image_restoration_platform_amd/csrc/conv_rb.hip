@@ -579,7 +579,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
             for (int m = 0; m < 2; ++m) {
                 const f32x16_t& c = acc[m][j];
                 unsigned x0, x1, y0, y1;
-                if constexpr (WRES) {      // bias already in the accumulators
+                if constexpr (C::DIRECT) {      // bias already in the accumulators (they start at it)
                     x0 = rb_pack(c[8 * pp + 0], c[8 * pp + 1]); x1 = rb_pack(c[8 * pp + 2], c[8 * pp + 3]);
                     y0 = rb_pack(c[8 * pp + 4], c[8 * pp + 5]); y1 = rb_pack(c[8 * pp + 6], c[8 * pp + 7]);
                 } else {
@@ -678,7 +678,23 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
             else if constexpr (PAR == 1) { if (sq0.kc == nkc - 1) epi_prefetch(sq0.it); }   // nkc is even: items end on odd stages
         }
 
-        if constexpr (!WRES) { if (sq0.kc == 0) zero_acc(); }   // WRES (nkc == 1): step 0 accumulates onto an inline 0   // new item (not in the epilogue: 64 dead registers there)
+        if constexpr (!WRES) {           // WRES (nkc == 1): step 0 accumulates onto the bias registers
+            if (sq0.kc == 0) {           // new item (not in the epilogue: 64 dead registers there)
+                if constexpr (C::DIRECT) {
+                    // accumulators start at the bias (permuted rows: accumulator i of lane-half h is cout j*32 + 16(i>>3) + 8h + (i&7)):
+                    // 4*NTL LDS reads per item replace 32*NTL epilogue adds; the moves take the place of the zeroing
+                    const float* bl = reinterpret_cast<const float*>(smem + C::MAIN_BYTES + C::RED_BYTES + C::COEF_BYTES) + sq0.it.nb * NT + 8 * h;
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 bv = *reinterpret_cast<const float4*>(bl + j * 32 + 16 * (q >> 1) + 4 * (q & 1));
+#pragma unroll
+                            for (int m = 0; m < 2; ++m) { acc[m][j][4 * q + 0] = bv.x; acc[m][j][4 * q + 1] = bv.y; acc[m][j][4 * q + 2] = bv.z; acc[m][j][4 * q + 3] = bv.w; }
+                        }
+                } else zero_acc();
+            }
+        }
         // (4) 18 MFMA k-steps from the current buffer, the s+1 transform interleaved between groups
         const int wsel = WRES ? (sq0.kc * C::W_BYTES) : 0;   // resident: slab of this kc
         const unsigned char* wb = w_cur + wsel + b_off;
