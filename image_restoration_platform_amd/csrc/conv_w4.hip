@@ -88,11 +88,12 @@ struct W4Cfg {
     static constexpr int MAIN_BYTES = W_BASE + 3 * W_BYTES;
     static constexpr int RED_BYTES = WAVES * 8 * 2 * 4;        // [waves][8 slots of 16 couts][sum, sumsq]
     static constexpr int BIAS_BYTES = 256 * 4;
-    static constexpr int LDS_BYTES = MAIN_BYTES + RED_BYTES + BIAS_BYTES;
+    static constexpr int COEF_BYTES = WAVES * 128;             // FUSED: per wave, 16 channels x (A, B) of the stage being staged
+    static constexpr int LDS_BYTES = MAIN_BYTES + RED_BYTES + BIAS_BYTES + COEF_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int NT, int WAVES, bool RESID, bool UPS, int DBG = 0>
+template <int NT, int WAVES, bool RESID, bool UPS, int DBG = 0, bool FUSED = false>
 __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
     using C = W4Cfg<NT, WAVES>;
     using Regs = W4Regs<C::IN_ITERS>;
@@ -169,13 +170,45 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < C::IN_ITERS; ++i) load_chunk(si, i, R);
     };
-    auto store_chunk = [&](int i, const Regs& R, uint4* lds_in) {   // plain copy; zero padding outside the image
+    // FUSED: y = silu(x*A + B) with (A, B) = GroupNorm+FiLM coefficients of the channel (gn_finalize), applied while staging, two
+    // channels at a time in packed f32 (as conv_rb.hip::transform_word); zero padding applies AFTER the activation.
+    // The coefficients of a stage's 16 channels travel global -> 8 lanes' float4 (fetched with the stage's input, a stage
+    // ahead) -> this wave's own 128-B LDS slot -> every lane's 8 (A, B) pairs: wave-local ordering, no barrier.
+    float* coef_lds = reinterpret_cast<float*>(smem + C::MAIN_BYTES + C::RED_BYTES + C::BIAS_BYTES) + wave * 32;
+    auto fetch_coeffs = [&](const StageInfo& si) -> float4 {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (FUSED) v = reinterpret_cast<const float4*>(a.ab + (size_t)si.it.img * Cin + si.kc * 16)[lane & 7];
+        return v;
+    };
+    float cA[8], cB[8];
+    auto stage_coeffs = [&](const float4& v) {          // publish to the wave's slot, read back this lane's half (c8)
+        if constexpr (FUSED) {
+            if (lane < 8) reinterpret_cast<float4*>(coef_lds)[lane] = v;
+            const float4* ab = reinterpret_cast<const float4*>(coef_lds + c8_fixed * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float4 t = ab[e]; cA[2 * e] = t.x; cB[2 * e] = t.y; cA[2 * e + 1] = t.z; cB[2 * e + 1] = t.w; }
+        }
+    };
+    auto transform_word = [&](unsigned w, int d) -> unsigned {
+        const f32x2_t x = {w4_lo(w), w4_hi(w)};
+        const f32x2_t A = {cA[2 * d], cA[2 * d + 1]}, B = {cB[2 * d], cB[2 * d + 1]};
+        const f32x2_t y = __builtin_elementwise_fma(x, A, B);
+        const f32x2_t t = y * (-1.4426950408889634f);
+        f32x2_t e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+        e = e + 1.0f;
+        const f32x2_t rinv = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+        const f32x2_t sv = y * rinv;
+        return w4_pack(sv.x, sv.y);
+    };
+    auto store_chunk = [&](int i, const Regs& R, uint4* lds_in) {   // copy (or activate); zero padding outside the image
         int t2 = tid;
         asm volatile("" : "+v"(t2));
         const int idx = t2 + i * C::THREADS;
         const bool ok = (R.ok >> i) & 1u;
         const u32x4_t zero = {0u, 0u, 0u, 0u};
-        const u32x4_t o = ok ? R.v[i] : zero;
+        u32x4_t v = R.v[i];
+        if constexpr (FUSED) { v.x = transform_word(v.x, 0); v.y = transform_word(v.y, 1); v.z = transform_word(v.z, 2); v.w = transform_word(v.w, 3); }
+        const u32x4_t o = ok ? v : zero;
         const int slot = c8_fixed * (W4_IN_CHUNKS / 2) + (idx >> 1);
         reinterpret_cast<u32x4_t*>(lds_in)[idx < W4_IN_CHUNKS ? slot : W4_IN_CHUNKS] = o;
     };
@@ -208,7 +241,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
     };
     // residual prefetch state lives across the item's last stage: the first RD-1 groups are requested BEFORE that stage's
     // MFMAs (k-steps 0..3 carry no other VMEM), so the epilogue finds them landed
-    constexpr int RD = 4;                            // residual groups in flight
+    constexpr int RD = FUSED ? 2 : 4;                // residual groups in flight (the fused variant has 16 registers of coefficients live)
     uint4 rv[RD][C::MT];
     unsigned offs[C::MT];
     bool inb[C::MT];
@@ -245,6 +278,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
     //   * k-steps 0..3 issue no VMEM at all; the single wait (vmcnt(0) at k-step 4) therefore only sees operations issued
     //     at least four k-steps earlier, and nothing is waited for at the stage end but the barrier.
     Regs R;
+    float4 cnext = make_float4(0.f, 0.f, 0.f, 0.f);   // FUSED: coefficients of the stage whose input R holds
     int widx = 0;                                   // weight slab of the current stage (s % 3)
     int par = 0;                                    // input tile of the current stage (s & 1)
     // ONE stage body in the loop (tile parity and slab index are run-time offsets): unrolling stage pairs made the
@@ -276,6 +310,10 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int i = 0; i < C::IN_ITERS; ++i) asm volatile("" : "+v"(R.v[i]));
+                if constexpr (FUSED) {            // coefficients of the data now in R (fetched with it, one stage ago)
+                    asm volatile("" : "+v"(cnext.x), "+v"(cnext.y), "+v"(cnext.z), "+v"(cnext.w));
+                    stage_coeffs(cnext);
+                }
                 if constexpr (LAST && RESID) {      // landed as well: tell the compiler, or it re-waits with its own (short) count
 #pragma unroll
                     for (int g = 0; g + 1 < RD; ++g)
@@ -295,6 +333,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
                     store_chunk(i, R, in_nxt);                           // stage s+1 input -> other tile
                     load_chunk(sq2, i, R);                              // stage s+2 input -> R.v[i]
                 }
+                if (FUSED && i == C::IN_ITERS) cnext = fetch_coeffs(sq2);   // after the last use of the old coefficients' data
                 if constexpr (!(DBG & 32)) {                            // slab s+2: 9 DMA issues over 5 k-steps
                     const unsigned char* ws = wslab(sq2);
                     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -421,6 +460,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
         float* bl = reinterpret_cast<float*>(smem + C::MAIN_BYTES + C::RED_BYTES);
         if (tid < a.cout && tid < 256) bl[tid] = a.bias[tid];
         load_stage(sq0, R);
+        if constexpr (FUSED) stage_coeffs(fetch_coeffs(sq0));
         const uint4* ws0 = reinterpret_cast<const uint4*>(wslab(sq0));
         const uint4* ws1 = reinterpret_cast<const uint4*>(wslab(sq1));
         uint4* wd = reinterpret_cast<uint4*>(smem + C::W_BASE);
@@ -429,6 +469,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < C::IN_ITERS; ++i) store_chunk(i, R, in0);
         load_stage(sq1, R);
+        if constexpr (FUSED) cnext = fetch_coeffs(sq1);
     }
     __syncthreads();
     // nkc is even (Cin/16 with Cin >= 128), so an item starts on an even stage and ends on an odd one
@@ -449,14 +490,14 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the workgroup's LDS is released
 }
 
-template <int NT, int WAVES, bool RESID, bool UPS, int DBG = 0>
+template <int NT, int WAVES, bool RESID, bool UPS, int DBG = 0, bool FUSED = false>
 void launch_w4(const ConvArgs& a, hipStream_t stream) {
     const int items = a.tiles_x * a.tiles_y * a.nimg * a.nblocks;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int grid = items < cus ? items : cus;
-    hipLaunchKernelGGL((conv_w4_kernel<NT, WAVES, RESID, UPS, DBG>), dim3(grid), dim3(WAVES * 64), 0, stream, a);
+    hipLaunchKernelGGL((conv_w4_kernel<NT, WAVES, RESID, UPS, DBG, FUSED>), dim3(grid), dim3(WAVES * 64), 0, stream, a);
     IRE_HIP(hipGetLastError());
 }
 
@@ -480,6 +521,7 @@ void conv_w4_launch(bool resid, const ConvArgs& a, hipStream_t stream) {
 #endif
     static const int waves = std::getenv("IRE_W4_WAVES") ? std::atoi(std::getenv("IRE_W4_WAVES")) : 8;
     if (waves == 4) { if (resid) launch_w4<128, 4, true, false>(a, stream); else launch_w4<128, 4, false, false>(a, stream); }
+    else if (a.ab != nullptr) { if (resid) launch_w4<128, 8, true, false, 0, true>(a, stream); else launch_w4<128, 8, false, false, 0, true>(a, stream); }
     else            { if (resid) launch_w4<128, 8, true, false>(a, stream); else launch_w4<128, 8, false, false>(a, stream); }
 }
 

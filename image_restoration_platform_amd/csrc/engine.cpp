@@ -58,6 +58,7 @@ Engine::Engine(const ire_config& cfg) {
     if (const char* v = std::getenv("IRE_ACT_SPLIT_MINC")) act_split_min_c_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_RB_PRIO")) prio_young_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_W4")) use_w4_ = std::atoi(v);
+    if (const char* v = std::getenv("IRE_W4_FUSED_MINC")) w4_fused_min_c_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_UP_RB_MINC")) up_rb_min_c_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_SLOT_STATS")) slot_stats_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_RB_STAMPS")) {   // diagnostic: "<cout>[r]" = stamp the first such ResBlock conv
@@ -502,7 +503,8 @@ void Engine::launch_conv(Lane& L, const ConvW& cw, const void* in0, const void* 
     else if (cw.kind == CONV_STEM) fam = FAM_STEM;
     else if (cw.kind == CONV_HEAD) fam = FAM_HEAD;
     prof_begin(fam, L.stream, flops, bytes);
-    const bool w4 = rb && rb_tile_h_ == kRbTileH && use_w4_ && ab == nullptr && cw.d_w4 != nullptr;
+    // conv_w4: pre-activated input (ab == nullptr) or, from w4_fused_min_c_ up, activation fused into its staging (8-wave form)
+    const bool w4 = rb && rb_tile_h_ == kRbTileH && use_w4_ && cw.d_w4 != nullptr && (ab == nullptr || cw.cout >= w4_fused_min_c_);
     if (a.stats) L.stat_parts = a.tiles_x * a.tiles_y;
     if (slot_stats_ && !w4 && !up_rb && rb && rb_tile_h_ == kRbTileH && a.stats) {
         a.stat_slots = conv_rb_stat_slots(ab != nullptr, a);
