@@ -58,15 +58,6 @@ __device__ __forceinline__ float w4_swap32_add(float v) {
     asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
     return x + y;
 }
-// sum over the 64 lanes of the wave (every lane ends up with the total)
-__device__ __forceinline__ float w4_wave_sum(float v) {
-    v = w4_ror_add<1>(v);
-    v = w4_ror_add<2>(v);
-    v = w4_ror_add<4>(v);
-    v = w4_ror_add<8>(v);
-    v = w4_swap16_add(v);
-    return w4_swap32_add(v);
-}
 
 struct W4Item { int img, ty, tx, nb, tile; };
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -217,13 +208,28 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
     };
 
     f32x16_t acc[C::MT][NTL];
-    auto zero_acc = [&]() {
+    // accumulators start at the bias (permuted slab rows: accumulator i of lane-half h is cout nb*NT + j*32 + 16(i>>3) + 8h + (i&7)):
+    // 4*NTL LDS reads per item instead of 16*NTL*MT adds in the epilogue; the moves take the place of the zeroing
+    constexpr bool BIAS_INIT = WAVES == 8;     // (the 512-register form keeps zeroing: a non-constant fill of 256 AGPRs spills)
+    auto zero_acc = [&](int nb) {
+        if constexpr (!BIAS_INIT) {
 #pragma unroll
-        for (int m = 0; m < C::MT; ++m)
+            for (int m = 0; m < C::MT; ++m)
 #pragma unroll
-            for (int j = 0; j < NTL; ++j)
+                for (int j = 0; j < NTL; ++j)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[m][j][i] = 0.f;
+                    for (int i = 0; i < 16; ++i) acc[m][j][i] = 0.f;
+            return;
+        }
+        const float* bl = reinterpret_cast<const float*>(smem + C::MAIN_BYTES + C::RED_BYTES) + nb * NT + 8 * h;
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bv = *reinterpret_cast<const float4*>(bl + j * 32 + 16 * (q >> 1) + 4 * (q & 1));
+#pragma unroll
+                for (int m = 0; m < C::MT; ++m) { acc[m][j][4 * q + 0] = bv.x; acc[m][j][4 * q + 1] = bv.y; acc[m][j][4 * q + 2] = bv.z; acc[m][j][4 * q + 3] = bv.w; }
+            }
     };
 
     float* red = reinterpret_cast<float*>(smem + C::MAIN_BYTES);                       // [4 waves][4 cc][4]
@@ -374,14 +380,23 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
             __builtin_amdgcn_sched_barrier(0);          // keep only one group's accumulator copies live
             if (g + RD - 1 < NTL * 2) load_resid(g + RD - 1, rv[(g + RD - 1) % RD]);
             // permuted slab rows (engine.cpp::make_conv): accumulators 8pp .. 8pp+7 are the 8 contiguous couts j*32 + 16pp + 8h + (0..7)
-            const float4 b0 = *reinterpret_cast<const float4*>(bias_lds + cout0 + j * 32 + 16 * pp + 8 * h_e);
-            const float4 b1 = *reinterpret_cast<const float4*>(bias_lds + cout0 + j * 32 + 16 * pp + 8 * h_e + 4);
+            float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;     // BIAS_INIT: the accumulators started at the bias
+            if constexpr (!BIAS_INIT) {
+                b0 = *reinterpret_cast<const float4*>(bias_lds + cout0 + j * 32 + 16 * pp + 8 * h_e);
+                b1 = *reinterpret_cast<const float4*>(bias_lds + cout0 + j * 32 + 16 * pp + 8 * h_e + 4);
+            }
             float ts = 0.f, tq = 0.f;
 #pragma unroll
             for (int m = 0; m < C::MT; ++m) {
                 const f32x16_t& c = acc[m][j];
-                const unsigned x0 = w4_pack(c[8 * pp + 0] + b0.x, c[8 * pp + 1] + b0.y), x1 = w4_pack(c[8 * pp + 2] + b0.z, c[8 * pp + 3] + b0.w);
-                const unsigned y0 = w4_pack(c[8 * pp + 4] + b1.x, c[8 * pp + 5] + b1.y), y1 = w4_pack(c[8 * pp + 6] + b1.z, c[8 * pp + 7] + b1.w);
+                unsigned x0, x1, y0, y1;
+                if constexpr (BIAS_INIT) {
+                    x0 = w4_pack(c[8 * pp + 0], c[8 * pp + 1]); x1 = w4_pack(c[8 * pp + 2], c[8 * pp + 3]);
+                    y0 = w4_pack(c[8 * pp + 4], c[8 * pp + 5]); y1 = w4_pack(c[8 * pp + 6], c[8 * pp + 7]);
+                } else {
+                    x0 = w4_pack(c[8 * pp + 0] + b0.x, c[8 * pp + 1] + b0.y); x1 = w4_pack(c[8 * pp + 2] + b0.z, c[8 * pp + 3] + b0.w);
+                    y0 = w4_pack(c[8 * pp + 4] + b1.x, c[8 * pp + 5] + b1.y); y1 = w4_pack(c[8 * pp + 6] + b1.z, c[8 * pp + 7] + b1.w);
+                }
                 unsigned w[4] = {x0, x1, y0, y1};
                 if constexpr (RESID) {
                     const uint4 rr = rv[g % RD][m];
@@ -474,7 +489,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
     __syncthreads();
     // nkc is even (Cin/16 with Cin >= 128), so an item starts on an even stage and ends on an odd one
     for (int k = 0; k < my_items; ++k) {
-        zero_acc();
+        zero_acc(sq0.it.nb);
         // steady-state stages, then the item's last stage peeled with the epilogue: a conditional epilogue inside the
         // loop makes the allocator split live ranges of in-flight prefetch registers mid-stage (vmcnt(0) + v_mov)
         for (int kc = 0; kc + 1 < nkc; ++kc) {
