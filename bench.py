@@ -4,16 +4,29 @@
 Workload (BASELINE.json metric): 1024x1024 RGB, batch 8 per GPU, synthetic,
 inputs resident in HBM when the timed region starts; a "step" = one batch through
 ire_restore_device (fused classifier scan + 43-conv U-Net + u8 store).  N > 1: one process per
-GPU, images sharded per rank with NO data-path collective (jobs are independent:
-restorator.js:198-211); only the timing barrier / max uses torch.distributed (RCCL).
+GPU, images sharded per rank (sharding.shard_range) with NO data-path collective (jobs are
+independent: restorator.js:198-211); only the timing barrier / max (sharding.timed_region) uses
+torch.distributed (RCCL).
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself: N fresh child
+processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set), created before this
+process imports torch or touches a GPU; the parent only waits and relays rank 0's JSON line.  Under
+torchrun (WORLD_SIZE set) it is a rank.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (the 3x3 conv family,
 HIP-event timed inside the engine on the launching stream) and `cpu_baseline` (the CPU oracle --
 test infrastructure -- timed on this box's host cores, N=1 only).
+
+Other workloads of the same path (--workload): `fusion` = cfg 3 (3 views restored -- one per rank of a
+fusion group when N >= 3 -- gathered point-to-point, aligned and blended); `classify` = the 7-score
+scan alone; `tiled` = cfg 4 (one 2048x2048 image restored in row strips with per-layer halo exchange
+and a per-GroupNorm gather of partial statistics; --precision fp8 for the C >= 128 convs).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,7 +34,60 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md chip table
+MFMA_FP8_PEAK_TFLOPS = 5000.0   # dense fp8 (block-scaled MFMA), same table
 HBM_PEAK_GBS = 8000.0
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=None, help="image side (default 1024; 2048 for --workload tiled)")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("IRE_STREAMS", "1")),
+                    help="lanes (HIP streams) per engine; 2 is ~3 %% faster but overlapping kernels would skew the per-kernel event timing")
+    ap.add_argument("--workload", choices=["restore", "fusion", "classify", "tiled"], default="restore",
+                    help="restore = the BASELINE metric (default); fusion = cfg 3; classify = the 7-score scan alone; tiled = cfg 4")
+    ap.add_argument("--precision", choices=["bf16", "fp8"], default="bf16", help="fp8: OCP e4m3 operands for the C >= 128 ResBlock convs (cfg 4)")
+    ap.add_argument("--strips", type=int, default=8, help="tiled: row strips per image on ONE GPU (virtual ranks); with N > 1 ranks each rank owns one strip")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the in-engine HIP-event kernel timing")
+    ap.add_argument("--profile-all", action="store_true", help="time every kernel family (more events, ~5 %% slower)")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # tests only: gloo + a sleep instead of the GPU step
+    args = ap.parse_args(argv)
+    if args.size is None:
+        args.size = 2048 if args.workload == "tiled" else 1024
+    return args
+
+
+# ------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks (fresh processes, before anything here touches a GPU)
+# ------------------------------------------------------------------------------------------------------
+def launch_ranks(n, argv, timeout=None):
+    """Start n rank processes of this script and relay rank 0's stdout.  Returns the worst exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate(timeout=timeout)
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=120)
+        except subprocess.TimeoutExpired:
+            p.kill()          # the exact child we started
+            p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return rc
 
 
 def cpu_baseline(size, budget_s=25.0):
@@ -47,171 +113,239 @@ def cpu_baseline(size, budget_s=25.0):
                       f"PyTorch-CPU fp32 RestoreNet oracle ({cores} threads) {(t2 - t1) / n:.1f} s/image"}
 
 
-def aux_workload(args, eng, dev, rank, world, dist, torch, np, synth):
-    """Secondary workloads of the same path (not the headline metric): HBM-roofline lines for the byte kernels."""
-    S, B = args.size, args.batch
-    if args.workload == "fusion":
-        x = torch.from_numpy(np.ascontiguousarray(synth.fusion_views(S, S, seed=7 + rank))).to(dev)
-        unit_bytes, units, fam, label = 4.0 * 3 * S * S, 1, "fusion", "3-view align + blend @%dx%d" % (S, S)
-        step = lambda: eng.fuse_tensor(x, noise_score=-1.0)
-        metric = "fused images/sec @3x%dx%d" % (S, S)
-    else:
-        x = torch.from_numpy(synth.batch(B, S, S, start=rank * B)).to(dev)
-        jp = torch.ones(B, dtype=torch.uint8, device=dev)
-        unit_bytes, units, fam, label = 3.0 * S * S, B, "classifier", "7-score classifier scan @%dx%d bs=%d" % (S, S, B)
-        step = lambda: eng.classify_tensor(x, jp)
-        metric = "classified images/sec @%dx%d bs=%d" % (S, S, B)
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    eng.profile_reset()
-    eng.profile_enable(1)
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    eng.profile_enable(0)
-    pf = eng.profile_query(fam)
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    if rank == 0:
-        ach = unit_bytes * units * args.steps / (pf["ms"] * 1e-3) / 1e9 if pf["ms"] > 0 else 0.0
-        print(json.dumps({
-            "metric": metric, "value": world * args.steps * units / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": label, "parallelism": "independent units x%d, no collective" % world},
-            "roofline": {"kernel": fam + " family (all its kernels, summed per step)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_step": unit_bytes * units, "family_ms_per_step": pf["ms"] / args.steps}}))
+class Ctx:
+    """Rank context: distributed state + the timing contract (sharding.timed_region)."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        from image_restoration_platform_amd import sharding
+        self.args, self.torch, self.dist, self.sharding = args, torch, dist, sharding
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != max(1, args.gpus) and self.rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}: reporting n_gpus={self.world}", file=sys.stderr)
+        if args.stub:
+            self.dev = torch.device("cpu")
+            backend = "gloo"
+        else:
+            if not torch.cuda.is_available():
+                raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+            torch.cuda.set_device(self.local_rank)
+            self.dev = torch.device("cuda", self.local_rank)
+            backend = "nccl"
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            kw = {} if args.stub else {"device_id": self.dev}
+            dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
+
+    def sync(self):
+        if not self.args.stub:
+            self.torch.cuda.synchronize()
+
+    def timed(self, step, before=None):
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides, MAX over ranks."""
+        for i in range(self.args.warmup):
+            step(-1 - i)
+        self.sync()
+        if before is not None:
+            before()
+        return self.sharding.timed_region(step, self.args.steps, self.sync)
+
+    def close(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--size", type=int, default=1024)
-    ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("IRE_STREAMS", "1")),
-                    help="lanes (HIP streams) per engine; 2 is ~3 %% faster but overlapping kernels would skew the per-kernel event timing")
-    ap.add_argument("--workload", choices=["restore", "fusion", "classify"], default="restore",
-                    help="restore = the BASELINE metric (default); fusion = 3-view align+blend @size^2 (cfg 3); classify = the 7-score scan alone")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="skip the in-engine HIP-event kernel timing")
-    ap.add_argument("--profile-all", action="store_true", help="time every kernel family (more events, ~5 %% slower)")
-    args = ap.parse_args()
+def line(ctx, metric, value, dt, dtype, config, extra=None):
+    a = ctx.args
+    res = {"metric": metric, "value": value, "unit": "images/sec", "n_gpus": ctx.world, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
+           "data": "synthetic", "config": config}
+    res.update(extra or {})
+    return res
 
+
+# ------------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------------
+def run_stub(ctx):
+    """Test stand-in for the GPU step (tests/test_distributed.py): the same sharding, timing and reporting code over gloo."""
+    a = ctx.args
+    lo, hi = ctx.sharding.shard_range(a.batch * ctx.world, ctx.rank, ctx.world)
+    dt = ctx.timed(lambda i: time.sleep(0.002 * (ctx.rank + 1)))
+    if ctx.rank == 0:
+        print(json.dumps(line(ctx, "stub images/sec", ctx.world * a.steps * a.batch / dt, dt, "u8",
+                              {"workload": "stub", "shard_of_rank0": [lo, hi], "global_batch": a.batch * ctx.world})))
+
+
+def run_restore(ctx, eng):
     import numpy as np
-    import torch
-    import torch.distributed as dist
     from image_restoration_platform_amd import synth, weights
-    from image_restoration_platform_amd.engine import Engine
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
-
-    B, S = args.batch, args.size
-    eng = Engine(device_index=local_rank, max_batch=B, num_streams=args.streams)
-    if args.workload != "restore":
-        aux_workload(args, eng, dev, rank, world, dist, torch, np, synth)
-        if world > 1:
-            dist.destroy_process_group()
-        return
-    # per-rank shard of the job stream: rank r restores images r*B .. r*B+B-1
-    x = torch.from_numpy(synth.batch(B, S, S, start=rank * B)).to(dev)
-    jpeg = torch.ones(B, dtype=torch.uint8, device=dev)
+    a, torch = ctx.args, ctx.torch
+    B, S = a.batch, a.size
+    # per-rank shard of the job stream (weak scaling: B images per rank): rank r restores images [lo, hi)
+    lo, hi = ctx.sharding.shard_range(B * ctx.world, ctx.rank, ctx.world)
+    x = torch.from_numpy(synth.batch(hi - lo, S, S, start=lo)).to(ctx.dev)
+    jpeg = torch.ones(hi - lo, dtype=torch.uint8, device=ctx.dev)
     out = torch.empty_like(x)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]    # per-step GPU time, no host sync inside
 
-    def step():
+    def step(i):
+        if i >= 0:
+            marks[i].record()
         eng.restore_tensor(x, out, scores=None, is_jpeg_u8=jpeg)
+        if i == a.steps - 1:
+            marks[a.steps].record()
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
+    def start_profile():                       # after the warm-up: the in-engine per-kernel event timing covers the timed steps only
+        if not a.no_profile:
+            eng.profile_reset()
+            eng.profile_enable(1 if a.profile_all else 2)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    if not args.no_profile:
-        eng.profile_reset()
-        eng.profile_enable(1 if args.profile_all else 2)
-    barrier()
-    torch.cuda.synchronize()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]    # per-step GPU time, no host sync inside
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        marks[i].record()
-        step()
-    marks[args.steps].record()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    dt = ctx.timed(step, before=start_profile)
     prof = None
-    if not args.no_profile:
+    if not a.no_profile:
         eng.profile_enable(0)
         prof = {f: eng.profile_query(f) for f in ("conv3x3", "conv1x1", "stem", "head", "classifier", "gn_finalize", "all")}
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    if rank == 0:
-        f3, f1 = weights.conv_flops(S, S)
-        res = {
-            "metric": "restored images/sec @%dx%d bs=%d" % (S, S, B),
-            "value": world * args.steps * B / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "step_ms_p50": step_ms[len(step_ms) // 2], "step_ms_p95": step_ms[min(len(step_ms) - 1, int(0.95 * len(step_ms)))],
-            "config": {"workload": "%dx%d RGB u8, batch %d per GPU: fused classifier scan + RestoreNet-v0 (43 convs, "
-                                   "%.1f GFLOP/image), seeded random-init weights" % (S, S, B, (f3 + f1) / 1e9),
-                       "global_batch": B * world, "parallelism": "per-image data parallel x%d, no collective" % world,
-                       "streams": args.streams},
-        }
-        if prof is not None:
-            c3 = prof["conv3x3"]
-            # HBM bytes per launch from PMC counters cannot be collected from inside this process; they come from the
-            # committed rocprofv3 --pmc passes of this same command (profiles/r01_traffic.json, FETCH_SIZE doubled per
-            # MI355X_MICROARCH.md), valid for the default 1024x1024 bs=8 workload only.
-            traffic, traffic_src = None, None
-            tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if ctx.rank != 0:
+        return
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    f3, f1 = weights.conv_flops(S, S)
+    res = line(ctx, "restored images/sec @%dx%d bs=%d" % (S, S, B), ctx.world * a.steps * B / dt, dt, "bf16", {
+        "workload": "%dx%d RGB u8, batch %d per GPU: fused classifier scan + RestoreNet-v0 (43 convs, %.1f GFLOP/image), "
+                    "seeded random-init weights" % (S, S, B, (f3 + f1) / 1e9),
+        "global_batch": B * ctx.world, "parallelism": "per-image data parallel x%d, no collective" % ctx.world, "streams": a.streams},
+        {"step_ms_p50": step_ms[len(step_ms) // 2], "step_ms_p95": step_ms[min(len(step_ms) - 1, int(0.95 * len(step_ms)))]})
+    if prof is not None:
+        c3 = prof["conv3x3"]
+        # HBM bytes per launch from PMC counters cannot be collected from inside this process; they come from the committed
+        # rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled per MI355X_MICROARCH.md), valid for 1024x1024 bs=8 only.
+        traffic, traffic_src = None, None
+        for name in ("r02_traffic.json", "r01_traffic.json"):
+            tj = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tj) and S == 1024 and B == 8:
                 with open(tj) as f:
                     tr = json.load(f)
-                traffic, traffic_src = tr["hbm_bytes_per_launch"], "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-            ach = c3["flops"] / (c3["ms"] * 1e-3) / 1e12 if c3["ms"] > 0 else 0.0
-            res["roofline"] = {
-                "kernel": "conv3x3 family: conv_rb_kernel + conv_w4_kernel (3x3 C->C and up convs) + stride-2 conv_mfma_kernel", "bound": "mfma",
-                "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
-                "traffic": traffic, "traffic_source": traffic_src, "launches": c3["launches"], "avg_launch_us": 1e3 * c3["ms"] / max(1, c3["launches"]),
-                "algorithmic_gflop_per_launch": c3["flops"] / max(1, c3["launches"]) / 1e9,
-                "hbm_algorithmic_GBs": c3["bytes"] / (c3["ms"] * 1e-3) / 1e9 if c3["ms"] > 0 else 0.0,
-                "family_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
-            }
-            res["whole_net_mfma_frac"] = (f3 + f1) * B * args.steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(S)
-        print(json.dumps(res))
-    if world > 1:
-        dist.destroy_process_group()
+                traffic, traffic_src = tr["hbm_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % name
+                break
+        ach = c3["flops"] / (c3["ms"] * 1e-3) / 1e12 if c3["ms"] > 0 else 0.0
+        res["roofline"] = {
+            "kernel": "conv3x3 family: every 3x3 convolution kernel of the step (ResBlock, up, stride-2 down)", "bound": "mfma",
+            "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+            "traffic": traffic, "traffic_source": traffic_src, "launches": c3["launches"], "avg_launch_us": 1e3 * c3["ms"] / max(1, c3["launches"]),
+            "algorithmic_gflop_per_launch": c3["flops"] / max(1, c3["launches"]) / 1e9,
+            "hbm_algorithmic_GBs": c3["bytes"] / (c3["ms"] * 1e-3) / 1e9 if c3["ms"] > 0 else 0.0,
+            "family_ms_per_step": {k: v["ms"] / a.steps for k, v in prof.items()},
+        }
+        res["whole_net_mfma_frac"] = (f3 + f1) * B * a.steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS
+    if ctx.world == 1 and not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(S)
+    print(json.dumps(res))
+
+
+def run_classify(ctx, eng):
+    from image_restoration_platform_amd import synth
+    a, torch = ctx.args, ctx.torch
+    S, B = a.size, a.batch
+    lo, hi = ctx.sharding.shard_range(B * ctx.world, ctx.rank, ctx.world)
+    x = torch.from_numpy(synth.batch(hi - lo, S, S, start=lo)).to(ctx.dev)
+    jp = torch.ones(hi - lo, dtype=torch.uint8, device=ctx.dev)
+
+    def step(i):
+        eng.classify_tensor(x, jp)
+
+    def start_profile():
+        eng.profile_reset()
+        eng.profile_enable(1)
+
+    dt = ctx.timed(step, before=start_profile)
+    eng.profile_enable(0)
+    pf = eng.profile_query("classifier")
+    if ctx.rank == 0:
+        unit_bytes = 3.0 * S * S
+        ach = unit_bytes * B * a.steps / (pf["ms"] * 1e-3) / 1e9 if pf["ms"] > 0 else 0.0
+        print(json.dumps(line(ctx, "classified images/sec @%dx%d bs=%d" % (S, S, B), ctx.world * a.steps * B / dt, dt, "u8", {
+            "workload": "7-score classifier scan @%dx%d bs=%d" % (S, S, B), "parallelism": "independent units x%d, no collective" % ctx.world}, {
+            "roofline": {"kernel": "classifier family (scan + finalize, summed per step)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_step": unit_bytes * B,
+                         "family_ms_per_step": pf["ms"] / a.steps}})))
+
+
+def run_fusion(ctx, eng):
+    """cfg 3.  N >= 3: ranks are dealt into fusion groups of 3 (sharding.fusion_groups); every rank of a group restores ITS view
+    of the scene, the restored views travel to the group's first rank point-to-point (two peers, two xGMI links), which aligns
+    and blends them (sharding.restore_views_and_fuse).  Ranks left over (and every rank when N < 3) run the whole 3-view job
+    alone: restore the 3 views as one batch of 3, fuse.  value = fused images/sec over the whole job."""
+    import numpy as np
+    from image_restoration_platform_amd import synth
+    a, torch, sh = ctx.args, ctx.torch, ctx.sharding
+    S = a.size
+    groups = sh.fusion_groups(ctx.world) if ctx.world >= 3 else []
+    mine = next((g for g in groups if ctx.rank in g), None)
+    views_np = synth.fusion_views(S, S, seed=7 + (groups.index(mine) if mine else 100 + ctx.rank))
+    jp1 = torch.ones(1, dtype=torch.uint8, device=ctx.dev)
+    jp3 = torch.ones(3, dtype=torch.uint8, device=ctx.dev)
+    if mine is not None:
+        view = torch.from_numpy(np.ascontiguousarray(views_np[mine.index(ctx.rank)])).to(ctx.dev)
+
+        def step(i):
+            sh.restore_views_and_fuse(
+                view, mine, mine[0],
+                restore=lambda v: eng.restore_tensor(v[None], scores=None, is_jpeg_u8=jp1)[0],
+                fuse=lambda vs: eng.fuse_tensor(torch.stack(vs, 0), noise_score=-1.0)[0])
+    else:
+        views = torch.from_numpy(np.ascontiguousarray(views_np)).to(ctx.dev)
+        buf = torch.empty_like(views)
+
+        def step(i):
+            eng.restore_tensor(views, buf, scores=None, is_jpeg_u8=jp3)
+            eng.fuse_tensor(buf, noise_score=-1.0)
+
+    def start_profile():
+        eng.profile_reset()
+        eng.profile_enable(1)
+
+    dt = ctx.timed(step, before=start_profile)
+    eng.profile_enable(0)
+    pf = eng.profile_query("fusion")
+    jobs = len(groups) + (ctx.world - 3 * len(groups))          # one fused image per group and per lone rank, per step
+    if ctx.rank == 0:
+        unit_bytes = 4.0 * 3 * S * S                             # (k + 1) * 3 * H * W: read 3 views, write one image
+        n_f = max(1, a.steps)
+        ach = unit_bytes / (pf["ms"] / n_f * 1e-3) / 1e9 if pf["ms"] > 0 else 0.0
+        print(json.dumps(line(ctx, "fused images/sec @3x%dx%d (3 views restored, gathered, aligned, blended)" % (S, S), jobs * a.steps / dt, dt, "bf16", {
+            "workload": "cfg3: 3 views @%dx%d, RestoreNet-v0 each, Fusion-v0 align + blend" % (S, S),
+            "parallelism": ("%d fusion group(s) of 3 ranks: one view per rank, point-to-point gather to the fusing rank; %d lone rank(s) run whole jobs"
+                            % (len(groups), ctx.world - 3 * len(groups))) if groups else "whole 3-view job per rank, no exchange"}, {
+            "roofline": {"kernel": "fusion family (luma, SAD searches, blend) on rank 0", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": unit_bytes}})))
+
+
+def run_tiled(ctx, eng):
+    from image_restoration_platform_amd import tiled
+    tiled.bench(ctx, eng, line, MFMA_FP8_PEAK_TFLOPS if ctx.args.precision == "fp8" else MFMA_BF16_PEAK_TFLOPS)
+
+
+def run_rank(args):
+    ctx = Ctx(args)
+    try:
+        if args.stub:
+            return run_stub(ctx)
+        from image_restoration_platform_amd.engine import Engine
+        eng = Engine(device_index=ctx.local_rank, max_batch=max(args.batch, 3), num_streams=args.streams, precision=args.precision)
+        {"restore": run_restore, "classify": run_classify, "fusion": run_fusion, "tiled": run_tiled}[args.workload](ctx, eng)
+    finally:
+        ctx.close()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, argv))       # nothing in this process has touched a GPU (torch is not even imported)
+    run_rank(args)
 
 
 if __name__ == "__main__":

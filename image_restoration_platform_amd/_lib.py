@@ -18,6 +18,12 @@ class IreTimings(ctypes.Structure):
     _fields_ = [("classify_ms", ctypes.c_double), ("restore_ms", ctypes.c_double), ("total_ms", ctypes.c_double)]
 
 
+class IreEngineStats(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("queue_depth", ctypes.c_int32), ("batches", ctypes.c_int64),
+                ("images", ctypes.c_int64), ("last_batch", ctypes.c_int32), ("max_batch", ctypes.c_int32),
+                ("images_per_sec", ctypes.c_double)]
+
+
 # every symbol include/ire.h declares: (name, restype, argtypes)
 _vp, _i, _u8p = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
 SYMBOLS = {
@@ -36,7 +42,8 @@ SYMBOLS = {
     "ire_preprocess_plan": (_i, [_i, _i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "ire_preprocess": (_i, [_vp, _u8p, _i, _i, _i, _i, _u8p, _i, _i]),
     "ire_preprocess_device": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
-    "ire_submit": (_i, [_vp, _u8p, _i, _i, _i, ctypes.POINTER(_vp)]),
+    "ire_submit": (_i, [_vp, _u8p, _i, _i, _i, _vp, ctypes.POINTER(_vp)]),
+    "ire_get_stats": (_i, [_vp, ctypes.POINTER(IreEngineStats)]),
     "ire_poll": (_i, [_vp, _vp, _i, _u8p, _vp, ctypes.POINTER(IreTimings)]),
     "ire_debug_classifier_sums": (_i, [_vp, _i, _vp]),
     "ire_debug_capture": (_i, [_vp, _i]),

@@ -19,6 +19,7 @@ void set_last_error(int code, const std::string& msg) { (void)code; g_last_error
 // engine batches of up to max_batch equal-shape images.
 struct Job {
     int h, w, is_jpeg;
+    bool has_scores = false;
     std::vector<uint8_t> in, out;
     double scores[7];
     ire_timings t{};
@@ -51,12 +52,25 @@ struct ire_engine {
 
 namespace ire {
 
+// One engine call = one critical section on the host (mutex) AND on the GPU (Engine::enter/leave): the caller's stream first
+// waits for the previous call's completion event, so calls from several threads / streams never interleave kernels on
+// the shared workspaces.  leave() also runs when f throws: whatever was enqueued before the failure stays fenced.
+template <typename F>
+static void on_stream(Engine& E, hipStream_t s, F&& f) {
+    std::lock_guard<std::mutex> lk(E.mutex());
+    E.enter(s);
+    try { f(); } catch (...) { E.leave(s); throw; }
+    E.leave(s);
+}
+
 // Two-slot pipeline (host feeding is what limits scaling): pinned staging buffers, H2D on a copy-in stream,
 // classify + restore on the engine's main stream, D2H on a copy-out stream; while the GPU works on batch k the thread
 // gathers batch k+1 into the other slot and hands batch k-1's pixels back to its jobs.
 struct BatchSlot {
     uint8_t *pin_in = nullptr, *pin_out = nullptr, *d_in = nullptr, *d_out = nullptr, *pin_jp = nullptr, *d_jp = nullptr;
     double* pin_sc = nullptr;
+    double* pin_sc_in = nullptr;          // scores the jobs brought along (ire_submit(..., scores, ...))
+    uint8_t has_sc[64] = {};
     size_t cap = 0;                       // bytes of each image buffer
     hipEvent_t ev_in = nullptr, ev_c0 = nullptr, ev_c1 = nullptr, ev_out = nullptr;
     std::vector<std::shared_ptr<Job>> jobs;
@@ -74,6 +88,7 @@ static void slot_reserve(BatchSlot& S, size_t bytes, int max_batch) {
         IRE_HIP(hipEventCreateWithFlags(&S.ev_out, hipEventDisableTiming));
         IRE_HIP(hipHostMalloc((void**)&S.pin_jp, (size_t)max_batch));
         IRE_HIP(hipHostMalloc((void**)&S.pin_sc, sizeof(double) * 7 * (size_t)max_batch));
+        IRE_HIP(hipHostMalloc((void**)&S.pin_sc_in, sizeof(double) * 7 * (size_t)max_batch));
         IRE_HIP(hipMalloc((void**)&S.d_jp, (size_t)max_batch));
     }
     if (bytes <= S.cap) return;
@@ -90,7 +105,7 @@ static void slot_free(BatchSlot& S) {
     if (S.pin_in) { (void)hipHostFree(S.pin_in); (void)hipHostFree(S.pin_out); (void)hipFree(S.d_in); (void)hipFree(S.d_out); }
     if (S.ev_in) {
         (void)hipEventDestroy(S.ev_in); (void)hipEventDestroy(S.ev_c0); (void)hipEventDestroy(S.ev_c1); (void)hipEventDestroy(S.ev_out);
-        (void)hipHostFree(S.pin_jp); (void)hipHostFree(S.pin_sc); (void)hipFree(S.d_jp);
+        (void)hipHostFree(S.pin_jp); (void)hipHostFree(S.pin_sc); (void)hipHostFree(S.pin_sc_in); (void)hipFree(S.d_jp);
     }
     S = BatchSlot{};
 }
@@ -160,18 +175,23 @@ static void batcher_loop(ire_engine* E) {
         S.status = IRE_OK; S.err.clear(); S.busy = true;
         try {
             slot_reserve(S, ib * (size_t)E->eng->max_batch(), E->eng->max_batch());
-            for (int i = 0; i < n; ++i) { std::memcpy(S.pin_in + ib * i, S.jobs[i]->in.data(), ib); S.pin_jp[i] = (uint8_t)S.jobs[i]->is_jpeg; }
+            for (int i = 0; i < n; ++i) {
+                std::memcpy(S.pin_in + ib * i, S.jobs[i]->in.data(), ib); S.pin_jp[i] = (uint8_t)S.jobs[i]->is_jpeg;
+                S.has_sc[i] = S.jobs[i]->has_scores ? 1 : 0;
+                if (S.has_sc[i]) std::memcpy(S.pin_sc_in + 7 * i, S.jobs[i]->scores, sizeof(double) * 7);
+            }
             IRE_HIP(hipMemcpyAsync(S.d_in, S.pin_in, ib * n, hipMemcpyHostToDevice, cs));
             IRE_HIP(hipMemcpyAsync(S.d_jp, S.pin_jp, (size_t)n, hipMemcpyHostToDevice, cs));
             IRE_HIP(hipEventRecord(S.ev_in, cs));
             {
-                std::lock_guard<std::mutex> lk(E->eng->mutex());
                 hipStream_t ms = E->eng->main_stream();
-                IRE_HIP(hipStreamWaitEvent(ms, S.ev_in, 0));
-                IRE_HIP(hipEventRecord(S.ev_c0, ms));
-                E->eng->restore_device(S.d_in, n, S.h, S.w, nullptr, S.d_jp, S.d_out, ms);       // classify inside
-                IRE_HIP(hipMemcpyAsync(S.pin_sc, E->eng->scores_device(), sizeof(double) * 7 * n, hipMemcpyDeviceToHost, ms));
-                IRE_HIP(hipEventRecord(S.ev_c1, ms));
+                on_stream(*E->eng, ms, [&] {
+                    IRE_HIP(hipStreamWaitEvent(ms, S.ev_in, 0));
+                    IRE_HIP(hipEventRecord(S.ev_c0, ms));
+                    E->eng->restore_device_mixed(S.d_in, n, S.h, S.w, S.pin_sc_in, S.has_sc, S.d_jp, S.d_out, ms);   // classifies the jobs that brought no scores
+                    IRE_HIP(hipMemcpyAsync(S.pin_sc, E->eng->scores_device(), sizeof(double) * 7 * n, hipMemcpyDeviceToHost, ms));
+                    IRE_HIP(hipEventRecord(S.ev_c1, ms));
+                });
             }
             IRE_HIP(hipStreamWaitEvent(os, S.ev_c1, 0));
             IRE_HIP(hipMemcpyAsync(S.pin_out, S.d_out, ib * n, hipMemcpyDeviceToHost, os));
@@ -256,16 +276,16 @@ int ire_load_weights(ire_engine* e, const void* blob, size_t bytes) {
 }
 
 int ire_max_batch_for(ire_engine* e, int h, int w) {
-    if (!e || !e->eng || h <= 0 || w <= 0 || h > 8192 || w > 8192) return 0;
-    return e->eng->max_batch();
+    if (!e || !e->eng) return 0;
+    std::lock_guard<std::mutex> lk(e->eng->mutex());
+    return e->eng->capacity_for(h, w);
 }
 
 int ire_classify(ire_engine* e, const uint8_t* rgb, int n, int h, int w, int row_stride, const uint8_t* is_jpeg,
                  double* scores_out, int32_t* label_out) {
     return guarded([&] {
         Engine& E = eng(e);
-        std::lock_guard<std::mutex> lk(E.mutex());
-        E.classify_host(rgb, n, h, w, row_stride, is_jpeg, scores_out, label_out);
+        on_stream(E, E.main_stream(), [&] { E.classify_host(rgb, n, h, w, row_stride, is_jpeg, scores_out, label_out); });
     });
 }
 
@@ -273,8 +293,7 @@ int ire_restore(ire_engine* e, const uint8_t* rgb, int n, int h, int w, const do
                 uint8_t* out_rgb, ire_timings* t) {
     return guarded([&] {
         Engine& E = eng(e);
-        std::lock_guard<std::mutex> lk(E.mutex());
-        E.restore_host(rgb, n, h, w, scores, is_jpeg, out_rgb, t);
+        on_stream(E, E.main_stream(), [&] { E.restore_host(rgb, n, h, w, scores, is_jpeg, out_rgb, t); });
     });
 }
 
@@ -282,8 +301,7 @@ int ire_fuse(ire_engine* e, const uint8_t* rgb_views, int k, int h, int w, doubl
              int32_t* shifts_out, ire_timings* t) {
     return guarded([&] {
         Engine& E = eng(e);
-        std::lock_guard<std::mutex> lk(E.mutex());
-        fuse_host(E, rgb_views, k, h, w, noise_score, out_rgb, shifts_out, t);
+        on_stream(E, E.main_stream(), [&] { fuse_host(E, rgb_views, k, h, w, noise_score, out_rgb, shifts_out, t); });
     });
 }
 
@@ -291,8 +309,7 @@ int ire_classify_device(ire_engine* e, const uint8_t* d_rgb, int n, int h, int w
                         double* d_scores, int32_t* d_label, void* stream) {
     return guarded([&] {
         Engine& E = eng(e);
-        std::lock_guard<std::mutex> lk(E.mutex());
-        E.classify_device(d_rgb, n, h, w, d_is_jpeg, d_scores, d_label, (hipStream_t)stream);
+        on_stream(E, (hipStream_t)stream, [&] { E.classify_device(d_rgb, n, h, w, d_is_jpeg, d_scores, d_label, (hipStream_t)stream); });
     });
 }
 
@@ -300,8 +317,7 @@ int ire_restore_device(ire_engine* e, const uint8_t* d_rgb, int n, int h, int w,
                        const uint8_t* d_is_jpeg, uint8_t* d_out_rgb, void* stream) {
     return guarded([&] {
         Engine& E = eng(e);
-        std::lock_guard<std::mutex> lk(E.mutex());
-        E.restore_device(d_rgb, n, h, w, d_scores, d_is_jpeg, d_out_rgb, (hipStream_t)stream);
+        on_stream(E, (hipStream_t)stream, [&] { E.restore_device(d_rgb, n, h, w, d_scores, d_is_jpeg, d_out_rgb, (hipStream_t)stream); });
     });
 }
 
@@ -309,8 +325,7 @@ int ire_fuse_device(ire_engine* e, const uint8_t* d_rgb_views, int k, int h, int
                     uint8_t* d_out_rgb, int32_t* d_shifts, void* stream) {
     return guarded([&] {
         Engine& E = eng(e);
-        std::lock_guard<std::mutex> lk(E.mutex());
-        fuse_device(E, d_rgb_views, k, h, w, noise_score, d_out_rgb, d_shifts, (hipStream_t)stream);
+        on_stream(E, (hipStream_t)stream, [&] { fuse_device(E, d_rgb_views, k, h, w, noise_score, d_out_rgb, d_shifts, (hipStream_t)stream); });
     });
 }
 
@@ -325,8 +340,7 @@ int ire_preprocess(ire_engine* e, const uint8_t* rgb, int h, int w, int orientat
                    int out_w) {
     return guarded([&] {
         Engine& E = eng(e);
-        std::lock_guard<std::mutex> lk(E.mutex());
-        E.preprocess_host(rgb, h, w, orientation, max_dim, out_rgb, out_h, out_w);
+        on_stream(E, E.main_stream(), [&] { E.preprocess_host(rgb, h, w, orientation, max_dim, out_rgb, out_h, out_w); });
     });
 }
 
@@ -334,12 +348,24 @@ int ire_preprocess_device(ire_engine* e, const uint8_t* d_rgb, int h, int w, int
                           int out_h, int out_w, void* stream) {
     return guarded([&] {
         Engine& E = eng(e);
-        std::lock_guard<std::mutex> lk(E.mutex());
-        E.preprocess_device(d_rgb, h, w, orientation, max_dim, d_out_rgb, out_h, out_w, (hipStream_t)stream);
+        on_stream(E, (hipStream_t)stream, [&] { E.preprocess_device(d_rgb, h, w, orientation, max_dim, d_out_rgb, out_h, out_w, (hipStream_t)stream); });
     });
 }
 
-int ire_submit(ire_engine* e, const uint8_t* rgb, int h, int w, int is_jpeg, ire_job** job_out) {
+int ire_get_stats(ire_engine* e, ire_engine_stats* out) {
+    return guarded([&] {
+        Engine& E = eng(e);
+        if (!out || out->struct_size < sizeof(ire_engine_stats)) fail(IRE_ERR_INVALID_INPUT, "invalid ire_engine_stats.struct_size");
+        {
+            std::lock_guard<std::mutex> lk(E.mutex());
+            E.get_stats(out);
+        }
+        std::lock_guard<std::mutex> lk(e->qmu);
+        out->queue_depth = (int32_t)e->queue.size();
+    });
+}
+
+int ire_submit(ire_engine* e, const uint8_t* rgb, int h, int w, int is_jpeg, const double* scores, ire_job** job_out) {
     return guarded([&] {
         eng(e);
         if (!rgb || !job_out) fail(IRE_ERR_INVALID_INPUT, "invalid arguments to ire_submit");
@@ -347,6 +373,7 @@ int ire_submit(ire_engine* e, const uint8_t* rgb, int h, int w, int is_jpeg, ire
             fail(IRE_ERR_INVALID_INPUT, "invalid image size for restore: height and width must be multiples of 8, >= 16");
         auto j = std::make_shared<Job>();
         j->h = h; j->w = w; j->is_jpeg = is_jpeg ? 1 : 0;
+        if (scores) { std::memcpy(j->scores, scores, sizeof(double) * 7); j->has_scores = true; }
         j->in.assign(rgb, rgb + (size_t)h * w * 3);
         {
             std::lock_guard<std::mutex> lk(e->qmu);

@@ -26,7 +26,11 @@ inline void hip_check(hipError_t e, const char* what, const char* file, int line
         std::snprintf(buf, sizeof(buf), "internal: %s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
         // a lost / absent device is reported as 503 so the worker's retry policy applies
         int code = (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? IRE_ERR_UNAVAILABLE : IRE_ERR_INTERNAL;
-        if (code == IRE_ERR_UNAVAILABLE)
+        if (e == hipErrorOutOfMemory) {     // a retry (smaller batch / later) can succeed: 503, not an internal error
+            code = IRE_ERR_UNAVAILABLE;
+            (void)hipGetLastError();
+            std::snprintf(buf, sizeof(buf), "service unavailable: out of device memory (%s, %s:%d)", what, file, line);
+        } else if (code == IRE_ERR_UNAVAILABLE)
             std::snprintf(buf, sizeof(buf), "service unavailable: %s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
         throw Error{code, buf};
     }

@@ -36,6 +36,7 @@ struct ConvArgs {
     int group_size;              // cout / 8
     int stat_slots;              // 0: stats[nimg][tiles][8][2] per tile; > 0 (= grid size): stats[nimg][slots][8][2], one entry per workgroup
     int prio_young;              // conv_rb: raise the issue priority of waves 4-7
+    int w4_waves;                // conv_w4 on a pre-activated input (ab == nullptr): 8 (default) or 4 waves per workgroup
     unsigned long long* stamps;  // diagnostic builds only (IRE_RB_ABLATE, DBG bit 16): s_memtime stamps, else null
 };
 

@@ -534,8 +534,10 @@ void conv_w4_launch(bool resid, const ConvArgs& a, hipStream_t stream) {
         default: break;
     }
 #endif
-    static const int waves = std::getenv("IRE_W4_WAVES") ? std::atoi(std::getenv("IRE_W4_WAVES")) : 8;
-    if (waves == 4) { if (resid) launch_w4<128, 4, true, false>(a, stream); else launch_w4<128, 4, false, false>(a, stream); }
+    // fused activation (a.ab) exists in the 8-wave form only: the 4-wave form is for pre-activated inputs (engine.cpp passes
+    // a.w4_waves = 4 only then); asking for it with coefficients would silently skip GroupNorm+SiLU, so refuse
+    if (a.w4_waves == 4 && a.ab != nullptr) fail(IRE_ERR_INTERNAL, "internal: conv_w4 4-wave form has no fused activation");
+    if (a.w4_waves == 4) { if (resid) launch_w4<128, 4, true, false>(a, stream); else launch_w4<128, 4, false, false>(a, stream); }
     else if (a.ab != nullptr) { if (resid) launch_w4<128, 8, true, false, 0, true>(a, stream); else launch_w4<128, 8, false, false, 0, true>(a, stream); }
     else            { if (resid) launch_w4<128, 8, true, false>(a, stream); else launch_w4<128, 8, false, false>(a, stream); }
 }

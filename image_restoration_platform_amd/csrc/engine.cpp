@@ -4,6 +4,7 @@
 // (server-node/src/clients/geminiClient.js:32-97).
 #include "engine.hpp"
 
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -19,6 +20,10 @@ namespace {
 const int kWidths[4] = {32, 64, 128, 256};
 const int kFilmOff[4] = {0, 64, 192, 448};
 const int kFilmDim = 960;
+
+inline double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 inline unsigned short f32_to_bf16(float f) {
     uint32_t u;
@@ -58,6 +63,7 @@ Engine::Engine(const ire_config& cfg) {
     if (const char* v = std::getenv("IRE_ACT_SPLIT_MINC")) act_split_min_c_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_RB_PRIO")) prio_young_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_W4")) use_w4_ = std::atoi(v);
+    if (const char* v = std::getenv("IRE_W4_WAVES")) w4_waves_ = std::atoi(v) == 4 ? 4 : 8;
     if (const char* v = std::getenv("IRE_W4_FUSED_MINC")) w4_fused_min_c_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_UP_RB_MINC")) up_rb_min_c_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_SLOT_STATS")) slot_stats_ = std::atoi(v);
@@ -69,6 +75,7 @@ Engine::Engine(const ire_config& cfg) {
     IRE_HIP(hipStreamCreateWithFlags(&main_stream_, hipStreamNonBlocking));
     for (auto& ev : ev_) IRE_HIP(hipEventCreate(&ev));
     IRE_HIP(hipEventCreateWithFlags(&fork_ev_, hipEventDisableTiming));
+    IRE_HIP(hipEventCreateWithFlags(&busy_ev_, hipEventDisableTiming));
     lanes_.resize(num_lanes_);
     for (auto& L : lanes_) {
         IRE_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
@@ -128,6 +135,7 @@ Engine::~Engine() {
     }
     for (auto& ev : ev_) if (ev) (void)hipEventDestroy(ev);
     if (fork_ev_) (void)hipEventDestroy(fork_ev_);
+    if (busy_ev_) (void)hipEventDestroy(busy_ev_);
     for (auto& r : prof_) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto ev : ev_pool_) (void)hipEventDestroy(ev);
     if (main_stream_) (void)hipStreamDestroy(main_stream_);
@@ -336,7 +344,9 @@ void Engine::ensure_io(int n, int h, int w) {
     const size_t px = (size_t)h * w;
     if ((size_t)n <= io_cap_imgs_ && px <= io_cap_px_) return;
     IRE_HIP(hipDeviceSynchronize());
-    const size_t imgs = std::max<size_t>(std::max<size_t>(io_cap_imgs_, (size_t)max_batch_), (size_t)n);
+    // small shapes: room for a whole batch at once (no regrowth per n); large ones: what was asked for
+    const size_t want = px * 3 * (size_t)max_batch_ <= ((size_t)256 << 20) ? (size_t)max_batch_ : (size_t)n;
+    const size_t imgs = std::max<size_t>(std::max<size_t>(io_cap_imgs_, want), (size_t)n);
     const size_t cap_px = std::max(io_cap_px_, px);
     for (void* p : {(void*)d_in_, (void*)d_out_, (void*)d_jpeg_, (void*)d_sums_, (void*)d_scores_, (void*)d_label_,
                     (void*)d_cond_, (void*)d_film_})
@@ -353,6 +363,14 @@ void Engine::ensure_io(int n, int h, int w) {
     io_cap_px_ = cap_px;
 }
 
+void Engine::enter(hipStream_t s) {
+    IRE_HIP(hipSetDevice(device_));
+    if (busy_recorded_) IRE_HIP(hipStreamWaitEvent(s, busy_ev_, 0));
+}
+void Engine::leave(hipStream_t s) {
+    if (hipEventRecord(busy_ev_, s) == hipSuccess) busy_recorded_ = true;
+}
+
 void Engine::free_workspace() {
     for (void* p : ws_allocs_) (void)hipFree(p);
     ws_allocs_.clear();
@@ -363,29 +381,57 @@ void Engine::free_workspace() {
         L.stats = nullptr;
         L.ab = nullptr;
     }
-    ws_imgs_per_lane_ = ws_h_ = ws_w_ = 0;
+    ws_imgs_per_lane_ = ws_imgs_cap_ = ws_h_ = ws_w_ = 0;
+    ws_bytes_ = 0;
+}
+
+// activation workspace (engine.cpp::ensure_workspace) + the staging of the host entry points (ensure_io) of ONE image
+size_t Engine::bytes_per_image(int h, int w) const {
+    size_t b = 0;
+    for (int l = 0; l < 4; ++l) {
+        const size_t t = (size_t)(h >> l) * (w >> l) * kWidths[l] * 2;
+        b += t * (4 + (l < 3 ? 1 : 0) + (kWidths[l] >= act_split_min_c_ ? 1 : 0));
+    }
+    b += (size_t)ceil_div(h, 4) * ceil_div(w, 32) * 16 * 4 + 256 * sizeof(float2);
+    b += (size_t)h * w * 3 * 2;      // d_in_ / d_out_
+    return b;
+}
+
+int Engine::capacity_for(int h, int w) const {
+    if (h <= 0 || w <= 0 || h > 8192 || w > 8192 || h % 8 || w % 8 || h < 16 || w < 16) return 0;
+    size_t free_b = 0, total_b = 0;
+    if (hipSetDevice(device_) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+    // what this engine already holds for activations would be released on a change of shape
+    const double avail = 0.92 * ((double)free_b + (double)ws_bytes_);
+    const double n = avail / (double)bytes_per_image(h, w);
+    return n >= (double)max_batch_ ? max_batch_ : (int)n;
 }
 
 void Engine::ensure_workspace(int n, int h, int w) {
-    (void)n;
-    const int per = ceil_div(max_batch_, num_lanes_);
-    if (per == ws_imgs_per_lane_ && h == ws_h_ && w == ws_w_) return;
+    // sized by the batch actually asked for (grow-only per shape), not by max_batch: one 8192^2 image must not need 64 slots
+    if (h == ws_h_ && w == ws_w_ && n <= ws_imgs_cap_) return;
+    const int cap = (h == ws_h_ && w == ws_w_) ? std::max(n, ws_imgs_cap_) : n;
+    const int per = ceil_div(cap, num_lanes_);
     IRE_HIP(hipDeviceSynchronize());
     free_workspace();
-    for (auto& L : lanes_) {
-        for (int l = 0; l < 4; ++l) {
-            const size_t bytes = (size_t)per * (h >> l) * (w >> l) * kWidths[l] * 2;
-            for (int b = 0; b < 4; ++b) { L.act[l][b] = (unsigned short*)dalloc(bytes); ws_allocs_.push_back(L.act[l][b]); }
-            if (l < 3) { L.skip[l] = (unsigned short*)dalloc(bytes); ws_allocs_.push_back(L.skip[l]); }
-            if (kWidths[l] >= act_split_min_c_) { L.actbuf[l] = (unsigned short*)dalloc(bytes); ws_allocs_.push_back(L.actbuf[l]); }
+    auto alloc = [&](size_t bytes) { void* p = dalloc(bytes); ws_allocs_.push_back(p); ws_bytes_ += bytes; return p; };
+    try {
+        for (auto& L : lanes_) {
+            for (int l = 0; l < 4; ++l) {
+                const size_t bytes = (size_t)per * (h >> l) * (w >> l) * kWidths[l] * 2;
+                for (int b = 0; b < 4; ++b) L.act[l][b] = (unsigned short*)alloc(bytes);
+                if (l < 3) L.skip[l] = (unsigned short*)alloc(bytes);
+                if (kWidths[l] >= act_split_min_c_) L.actbuf[l] = (unsigned short*)alloc(bytes);
+            }
+            const size_t tiles0 = (size_t)ceil_div(h, 4) * ceil_div(w, 32);
+            L.stats = (float*)alloc((size_t)per * tiles0 * 16 * 4);
+            L.ab = (float2*)alloc((size_t)per * 256 * sizeof(float2));
         }
-        const size_t tiles0 = (size_t)ceil_div(h, 4) * ceil_div(w, 32);
-        L.stats = (float*)dalloc((size_t)per * tiles0 * 16 * 4);
-        L.ab = (float2*)dalloc((size_t)per * 256 * sizeof(float2));
-        ws_allocs_.push_back(L.stats);
-        ws_allocs_.push_back(L.ab);
+    } catch (...) {
+        free_workspace();     // a partial allocation must not pin HBM: the caller gets "service unavailable" and may retry smaller
+        throw;
     }
-    ws_imgs_per_lane_ = per; ws_h_ = h; ws_w_ = w;
+    ws_imgs_per_lane_ = per; ws_imgs_cap_ = per * num_lanes_; ws_h_ = h; ws_w_ = w;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -487,6 +533,7 @@ void Engine::launch_conv(Lane& L, const ConvW& cw, const void* in0, const void* 
     a.stamps = nullptr;
     a.stat_slots = 0;
     a.prio_young = prio_young_;
+    a.w4_waves = (ab == nullptr) ? w4_waves_ : 8;
     if (stamps_dev_ && rb && cw.cout == stamps_cout_ && (cw.kind == CONV_RB2) == stamps_resid_ && !stamps_taken_) {
         a.stamps = stamps_dev_;
         stamps_taken_ = true;
@@ -633,6 +680,12 @@ void Engine::restore_device(const uint8_t* d_rgb, int n, int h, int w, const dou
     film_launch(d_cond_, n, net_.d_film_w, net_.d_film_b, kFilmDim, d_film_, stream);
     prof_end(stream);
     last_n_ = n;
+    batches_run_ += 1; images_restored_ += n; last_batch_ = n;
+    {
+        const double t = now_s();
+        recent_.emplace_back(t, n);
+        while (!recent_.empty() && recent_.front().first < t - 10.0) recent_.pop_front();
+    }
 
     const int lanes_used = std::min(num_lanes_, n);
     const size_t img_bytes = (size_t)h * w * 3;
@@ -654,6 +707,33 @@ void Engine::restore_device(const uint8_t* d_rgb, int n, int h, int w, const dou
         IRE_HIP(hipEventRecord(L.done, L.stream));
         IRE_HIP(hipStreamWaitEvent(stream, L.done, 0));
     }
+}
+
+void Engine::restore_device_mixed(const uint8_t* d_rgb, int n, int h, int w, const double* host_scores, const uint8_t* has_scores,
+                                  const uint8_t* d_is_jpeg, uint8_t* d_out, hipStream_t stream) {
+    check_shape(n, h, w, true);
+    ensure_io(n, 1, 1);
+    bool any_missing = false, any_given = false;
+    for (int i = 0; i < n; ++i) { if (has_scores && has_scores[i]) any_given = true; else any_missing = true; }
+    if (!any_given) { restore_device(d_rgb, n, h, w, nullptr, d_is_jpeg, d_out, stream); return; }
+    if (any_missing) classify_device(d_rgb, n, h, w, d_is_jpeg, d_scores_, d_label_, stream);
+    for (int i = 0; i < n; ++i)
+        if (has_scores[i]) IRE_HIP(hipMemcpyAsync(d_scores_ + 7 * i, host_scores + 7 * i, sizeof(double) * 7, hipMemcpyHostToDevice, stream));
+    restore_device(d_rgb, n, h, w, d_scores_, d_is_jpeg, d_out, stream);
+}
+
+void Engine::get_stats(ire_engine_stats* out) {
+    out->batches = batches_run_;
+    out->images = images_restored_;
+    out->last_batch = last_batch_;
+    out->max_batch = max_batch_;
+    const double t = now_s();
+    while (!recent_.empty() && recent_.front().first < t - 10.0) recent_.pop_front();
+    double imgs = 0;
+    for (auto& r : recent_) imgs += r.second;
+    // span from the first call of the window to now; one lone call reports over >= 1 s so the gauge decays instead of spiking
+    const double span = recent_.empty() ? 1.0 : std::max(1.0, t - recent_.front().first);
+    out->images_per_sec = recent_.empty() ? 0.0 : imgs / span;
 }
 
 void Engine::classify_host(const uint8_t* rgb, int n, int h, int w, int row_stride, const uint8_t* is_jpeg, double* scores,

@@ -6,6 +6,7 @@
 // per-image working set of the full-resolution levels stays inside the 256 MiB Infinity Cache),
 // staging buffers for the host-pointer entry points, and an event-based per-kernel profiler.
 #pragma once
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -107,6 +108,20 @@ public:
     void profile_query(int fam, double* ms, int64_t* launches, double* flops, double* bytes);
 
     int max_batch() const { return max_batch_; }
+    // Cross-stream serialisation of the shared GPU scratch (activation workspaces, d_scores_, d_film_, fusion and
+    // preprocess scratch): every ABI call brackets its enqueue with enter/leave under the engine mutex.  enter makes the
+    // caller's stream wait for the completion event of the previous call (a no-op on the same stream), leave records
+    // the new one -- so two threads on two streams interleave whole calls on the GPU, never kernels of two calls.
+    void enter(hipStream_t s);
+    void leave(hipStream_t s);
+    // device bytes one more image of this shape costs (activation workspace + staging), and how many fit right now
+    size_t bytes_per_image(int h, int w) const;
+    int capacity_for(int h, int w) const;
+    void get_stats(ire_engine_stats* out);                            // counters + the images/sec gauge (queue_depth is the ABI layer's)
+    // batcher form of restore_device: rows of host_scores (pinned, n*7) flagged in has_scores are used as given, the rest are
+    // classified inside (one scan over the batch, skipped when every job brought its scores)
+    void restore_device_mixed(const uint8_t* d_rgb, int n, int h, int w, const double* host_scores, const uint8_t* has_scores,
+                              const uint8_t* d_is_jpeg, uint8_t* d_out, hipStream_t stream);
     hipStream_t main_stream() const { return main_stream_; }          // the stream of the host entry points and of the batcher's compute
     const double* scores_device() const { return d_scores_; }       // [last n][7], valid after a classify on main_stream()
     std::mutex& mutex() { return mu_; }
@@ -134,6 +149,7 @@ private:
     int num_lanes_ = 1;
     uint32_t flags_ = 0;
     int w4_fused_min_c_ = 128;      // IRE_W4_FUSED_MINC: ResBlock convs with fused activation and cout >= this run on conv_w4's fused variant
+    int w4_waves_ = 8;            // IRE_W4_WAVES=4: the one-wave-per-SIMD form, pre-activated inputs only (fused activation needs the 8-wave form)
     int use_w4_ = 1;              // C >= 128 ResBlock convs on conv_w4.hip (IRE_W4=0: conv_rb.hip; IRE_W4_WAVES=4|8)
     int up_rb_min_c_ = 32;        // `up` convs with cout >= this run on conv_rb.hip (IRE_UP_RB_MINC), the rest on the v1 kernel
     int slot_stats_ = 0;          // IRE_SLOT_STATS=1: per-workgroup GroupNorm partials at C = 32 (+2 % throughput, gives up bit-identity across batch compositions)
@@ -144,6 +160,12 @@ private:
     hipStream_t main_stream_ = nullptr;
     hipEvent_t ev_[4] = {};
     hipEvent_t fork_ev_ = nullptr;
+    hipEvent_t busy_ev_ = nullptr;   // completion of the last enqueued call (enter/leave)
+    bool busy_recorded_ = false;
+    int64_t batches_run_ = 0, images_restored_ = 0;
+    int last_batch_ = 0;
+    std::deque<std::pair<double, int>> recent_;      // (seconds since init, images) of the last 10 s of restore calls
+    double t0_ = 0.0;
 
     // classifier
     ClassifierTables tables_{};
@@ -177,7 +199,8 @@ private:
     Net net_;
     std::map<std::string, std::pair<std::vector<int>, std::vector<float>>> host_w_;
     std::vector<Lane> lanes_;
-    int ws_imgs_per_lane_ = 0, ws_h_ = 0, ws_w_ = 0;
+    int ws_imgs_per_lane_ = 0, ws_imgs_cap_ = 0, ws_h_ = 0, ws_w_ = 0;
+    size_t ws_bytes_ = 0;
     std::vector<void*> ws_allocs_;
 
     // debug / profile

@@ -30,14 +30,16 @@ def _ptr(a):
 
 
 class Engine:
-    def __init__(self, device_index=0, max_batch=8, num_streams=0, weights_path="default", seed=0, flags=0):
+    def __init__(self, device_index=0, max_batch=8, num_streams=0, weights_path="default", seed=0, flags=0, precision="bf16"):
         self._lib = _lib.load()
         if weights_path == "default":
             weights_path = _weights.ensure_default(seed)
         cfg = _lib.IreConfig()
         cfg.struct_size = ctypes.sizeof(_lib.IreConfig)
         cfg.device_index = device_index
-        cfg.precision = 0
+        if precision not in ("bf16", "fp8"):
+            raise EngineError(1, "invalid precision: 'bf16' or 'fp8'")
+        cfg.precision = 1 if precision == "fp8" else 0          # IRE_PRECISION_*
         cfg.max_batch = max_batch
         cfg.num_streams = num_streams
         cfg.weights_path = weights_path.encode() if weights_path else None
@@ -140,12 +142,26 @@ class Engine:
                                                     ctypes.c_void_p(out.data_ptr()), oh, ow, self._stream_ptr(stream)))
         return out
 
-    def submit(self, rgb, is_jpeg=True):
+    def submit(self, rgb, is_jpeg=True, scores=None):
+        """Queue one image with the engine's batcher (in-flight jobs of one shape coalesce into engine batches);
+        scores: the 7 scores a previous classify() returned for this image => it is not classified again."""
         rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
         h, w, _ = rgb.shape
+        sc = None if scores is None else np.ascontiguousarray(np.asarray(scores, dtype=np.float64).reshape(7))
         job = ctypes.c_void_p()
-        self._check(self._lib.ire_submit(self._h, _ptr(rgb), h, w, int(bool(is_jpeg)), ctypes.byref(job)))
+        self._check(self._lib.ire_submit(self._h, _ptr(rgb), h, w, int(bool(is_jpeg)), _ptr(sc), ctypes.byref(job)))
         return (job, h, w)
+
+    def stats(self):
+        """Service gauges (f4: getHealthStatus / the /health/ready dependency entry)."""
+        st = _lib.IreEngineStats()
+        st.struct_size = ctypes.sizeof(_lib.IreEngineStats)
+        self._check(self._lib.ire_get_stats(self._h, ctypes.byref(st)))
+        return {"queueDepth": st.queue_depth, "batches": st.batches, "images": st.images, "lastBatch": st.last_batch,
+                "maxBatch": st.max_batch, "imagesPerSec": st.images_per_sec}
+
+    def max_batch_for(self, h, w):
+        return int(self._lib.ire_max_batch_for(self._h, int(h), int(w)))
 
     def poll(self, job, timeout_ms=-1):
         handle, h, w = job

@@ -30,7 +30,9 @@ function createEngine(opts) {
   const lib = opts.libPath || path.join(__dirname, '..', 'lib', 'libire.so');
   // throws Error('service unavailable: ...') when there is no gfx950 device: there is no CPU fallback
   const handle = addon.init(lib, opts.weightsPath || '', opts.deviceIndex || 0, opts.maxBatch || 8, opts.numStreams || 0);
-  return { addon, handle };
+  // seen: Buffer -> {decoded, scores}: RestoratorService hands the SAME Buffer object first to classifier.analyze and then to
+  // geminiClient.restoreImage (restorator.js:59-94); remembering it here means one decode and one classification per job
+  return { addon, handle, seen: new WeakMap() };
 }
 
 function defaultCodec() {
@@ -76,6 +78,7 @@ function createEngineClassifier(opts) {
       const img = await codec.decode(imageBuffer); // rejects on undecodable input -> failureStage CLASSIFICATION
       const flags = Buffer.from([img.format === 'jpeg' ? 1 : 0]); // classifier.js:180 branches on the container
       const r = await engine.addon.classifyAsync(engine.handle, img.data, 1, img.height, img.width, flags);
+      if (engine.seen && Buffer.isBuffer(imageBuffer)) engine.seen.set(imageBuffer, { decoded: img, scores: Float64Array.from(r.scores.slice(0, 7)) });
       const out = {};
       KEYS.forEach((k, i) => { out[k] = r.scores[i]; });
       return out;
@@ -91,19 +94,30 @@ function createEngineRestorer(opts) {
     async restoreImage(args) {
       const images = args.images;
       if (!images || images.length < 1 || images.length > 3) throw new Error('invalid images: expected 1..3 encoded images');
-      const decoded = [];
-      for (const b of images) decoded.push(await codec.decode(b));
+      const decoded = [], known = [];
+      for (const b of images) {           // analyze() already decoded and classified this Buffer: reuse both
+        const hit = engine.seen && Buffer.isBuffer(b) ? engine.seen.get(b) : undefined;
+        known.push(hit ? hit.scores : null);
+        decoded.push(hit ? hit.decoded : await codec.decode(b));
+      }
       const w = decoded[0].width, h = decoded[0].height;
       if (decoded.some((d) => d.width !== w || d.height !== h)) throw new Error('invalid images: fusion views must have identical dimensions');
-      const restored = [];
+      // every view is queued with the engine's batcher at once (ire_submit on this thread, ire_poll on the libuv pool): the
+      // views of one call and the single-image jobs of the other in-flight calls (3 per batch, 5 per worker) share engine batches
       let W = w, H = h;
-      for (const d of decoded) {
+      const pending = decoded.map(async (d, i) => {
         const p = padToMultipleOf8(d);
         W = p.width; H = p.height;
         const flags = Buffer.from([d.format === 'jpeg' ? 1 : 0]);
-        const r = await engine.addon.restoreAsync(engine.handle, p.data, 1, p.height, p.width, flags); // classifies inside
-        restored.push(r.pixels);
-      }
+        let scores = known[i];
+        if (!scores && (p.width !== d.width || p.height !== d.height)) {
+          // the conditioning scores are those of the image itself (what analyze() reports), never of its replicate-padded copy
+          scores = Float64Array.from((await engine.addon.classifyAsync(engine.handle, d.data, 1, d.height, d.width, flags)).scores.slice(0, 7));
+        }
+        return scores ? engine.addon.restoreAsync(engine.handle, p.data, 1, p.height, p.width, flags, scores)   // scores known: not classified again
+                      : engine.addon.restoreAsync(engine.handle, p.data, 1, p.height, p.width, flags);          // classifies inside
+      });
+      const restored = (await Promise.all(pending)).map((r) => r.pixels);
       let pixels = restored[0];
       if (restored.length > 1) {
         if (H < 64 || W < 64) throw new Error('invalid images: fusion needs at least 64x64 pixels');
@@ -120,4 +134,33 @@ function createEngineRestorer(opts) {
   };
 }
 
-module.exports = { KEYS, createEngine, createEngineClassifier, createEngineRestorer, padToMultipleOf8 };
+// SURVEY 8(f) row 4.  Two shapes the reference already has:
+//  * checkEngine(): a dependency probe in the form healthRouter.js:4-73 uses ({info, ok[, degraded]}), to be listed beside
+//    redis / firestore / gcs in GET /health/ready (healthRouter.js:80-117): the deployer adds `engine: engineStatus.info` to
+//    `dependencies` and engineStatus to the two `.some(...)` lists (INTEGRATION.md section 1);
+//  * metrics(): the images/sec gauge and batch counters, to sit beside `metrics.requests` in the same payload.
+// The probe classifies a 16x16 black image on the GPU (~0.1 ms): it tells "no device / library" (unavailable) from "idle".
+function createEngineHealth(opts) {
+  const engine = opts.engine;
+  const probe = Buffer.alloc(16 * 16 * 3);
+  function metrics() {
+    const s = engine.addon.stats(engine.handle);
+    return { imagesPerSec: s.imagesPerSec, images: s.images, batches: s.batches, lastBatch: s.lastBatch, maxBatch: s.maxBatch, queueDepth: s.queueDepth };
+  }
+  async function checkEngine() {
+    const info = { status: 'ok', device: 'gfx950' };
+    try {
+      await engine.addon.classifyAsync(engine.handle, probe, 1, 16, 16, Buffer.from([0]));
+      Object.assign(info, metrics());
+      if (info.queueDepth > 4 * info.maxBatch) { info.status = 'degraded'; info.reason = 'engine queue is backing up'; return { info, ok: true, degraded: true }; }
+      return { info, ok: true };
+    } catch (error) {
+      info.status = 'unavailable';
+      info.error = error && error.message;
+      return { info, ok: false };
+    }
+  }
+  return { checkEngine, metrics };
+}
+
+module.exports = { KEYS, createEngine, createEngineClassifier, createEngineRestorer, createEngineHealth, padToMultipleOf8 };

@@ -30,6 +30,12 @@ struct Api {
     decltype(&ire_restore) restore = nullptr;
     decltype(&ire_fuse) fuse = nullptr;
     decltype(&ire_abi_version) abi_version = nullptr;
+    decltype(&ire_submit) submit = nullptr;
+    decltype(&ire_poll) poll = nullptr;
+    decltype(&ire_preprocess_plan) preprocess_plan = nullptr;
+    decltype(&ire_preprocess) preprocess = nullptr;
+    decltype(&ire_get_stats) get_stats = nullptr;
+    decltype(&ire_max_batch_for) max_batch_for = nullptr;
 } g;
 
 bool load_api(const char* path, std::string* err) {
@@ -39,6 +45,9 @@ bool load_api(const char* path, std::string* err) {
 #define SYM(field, name) g.field = (decltype(g.field))dlsym(g.so, name); if (!g.field) { *err = "service unavailable: missing symbol " name; return false; }
     SYM(init, "ire_init") SYM(shutdown, "ire_shutdown") SYM(last_error, "ire_last_error") SYM(classify, "ire_classify")
     SYM(restore, "ire_restore") SYM(fuse, "ire_fuse") SYM(abi_version, "ire_abi_version")
+    SYM(submit, "ire_submit") SYM(poll, "ire_poll") SYM(preprocess_plan, "ire_preprocess_plan") SYM(preprocess, "ire_preprocess")
+    SYM(get_stats, "ire_get_stats") SYM(max_batch_for, "ire_max_batch_for")
+    if (g.abi_version() != IRE_ABI_VERSION) { *err = "service unavailable: libire.so ABI version mismatch"; return false; }
 #undef SYM
     return true;
 }
@@ -50,7 +59,10 @@ double get_f64(napi_env env, napi_value v) { double x = 0; napi_get_value_double
 
 // ---- async job -------------------------------------------------------------------------------------
 struct Job {
-    enum Kind { CLASSIFY, RESTORE, FUSE } kind;
+    enum Kind { CLASSIFY, RESTORE, FUSE, PREPROCESS } kind;
+    ire_job* queued = nullptr;     // RESTORE with n == 1: already in the engine's batcher (ire_submit ran on the JS thread)
+    int orientation = 1, max_dim = 2048, out_w = 0, out_h = 0, resized = 0;
+    bool has_scores = false;
     ire_engine* eng;
     std::vector<uint8_t> in, jpeg, out;
     int n, h, w;
@@ -72,8 +84,17 @@ void execute(napi_env, void* data) {
             j->status = g.classify(j->eng, j->in.data(), j->n, j->h, j->w, 3 * j->w, j->jpeg.data(), j->scores.data(), j->labels.data());
             break;
         case Job::RESTORE:
-            j->out.resize(j->in.size());
-            j->status = g.restore(j->eng, j->in.data(), j->n, j->h, j->w, nullptr, j->jpeg.data(), j->out.data(), &j->t);
+            j->out.resize((size_t)j->n * j->h * j->w * 3);
+            if (j->queued) {          // the pool thread only waits: every in-flight job is already queued, so they coalesce
+                j->scores.resize(7);
+                j->status = g.poll(j->eng, j->queued, -1, j->out.data(), j->scores.data(), &j->t);
+            } else {
+                j->status = g.restore(j->eng, j->in.data(), j->n, j->h, j->w, j->has_scores ? j->scores.data() : nullptr, j->jpeg.data(), j->out.data(), &j->t);
+            }
+            break;
+        case Job::PREPROCESS:
+            j->out.resize((size_t)j->out_h * j->out_w * 3);
+            j->status = g.preprocess(j->eng, j->in.data(), j->h, j->w, j->orientation, j->max_dim, j->out.data(), j->out_h, j->out_w);
             break;
         case Job::FUSE:
             j->out.resize((size_t)j->h * j->w * 3); j->labels.resize(2 * j->n);
@@ -110,6 +131,18 @@ void complete(napi_env env, napi_status, void* data) {
             napi_set_named_property(env, res, "pixels", buf);
             napi_value ms; napi_create_double(env, j->t.restore_ms, &ms); napi_set_named_property(env, res, "restore_ms", ms);
             napi_create_double(env, j->t.classify_ms, &ms); napi_set_named_property(env, res, "classify_ms", ms);
+            if (j->kind == Job::PREPROCESS) {
+                napi_value v;
+                napi_create_int32(env, j->out_w, &v); napi_set_named_property(env, res, "width", v);
+                napi_create_int32(env, j->out_h, &v); napi_set_named_property(env, res, "height", v);
+                napi_get_boolean(env, j->resized != 0, &v); napi_set_named_property(env, res, "resized", v);
+            }
+            if (j->kind == Job::RESTORE && j->scores.size() >= 7) {      // the batcher's classification comes back with the pixels
+                napi_value ab2, ta2; void* p2;
+                napi_create_arraybuffer(env, 7 * 8, &p2, &ab2); std::memcpy(p2, j->scores.data(), 7 * 8);
+                napi_create_typedarray(env, napi_float64_array, 7, ab2, 0, &ta2);
+                napi_set_named_property(env, res, "scores", ta2);
+            }
             if (j->kind == Job::FUSE) {
                 napi_value ab, ta;
                 napi_create_arraybuffer(env, j->labels.size() * 4, &p, &ab); std::memcpy(p, j->labels.data(), j->labels.size() * 4);
@@ -159,7 +192,34 @@ napi_value submit(napi_env env, napi_callback_info info, Job::Kind kind) {
             jl >= (size_t)j->n)
             std::memcpy(j->jpeg.data(), jd, j->n);
     }
-    j->noise = argc > 6 ? get_f64(env, argv[6]) : -1.0;
+    j->noise = (kind == Job::FUSE && argc > 6) ? get_f64(env, argv[6]) : -1.0;
+    if (kind == Job::RESTORE && argc > 6) {      // scores of a previous analyze() of this image: the engine will not classify it again
+        bool is_ta = false;
+        if (napi_is_typedarray(env, argv[6], &is_ta) == napi_ok && is_ta) {
+            napi_typedarray_type tt; size_t tl; void* td; napi_value tab; size_t toff;
+            if (napi_get_typedarray_info(env, argv[6], &tt, &tl, &td, &tab, &toff) == napi_ok && tt == napi_float64_array && tl >= 7 * (size_t)j->n) {
+                j->scores.assign((double*)td, (double*)td + 7 * (size_t)j->n);
+                j->has_scores = true;
+            }
+        }
+    }
+    if (kind == Job::RESTORE && j->n == 1) {
+        // single-image jobs (the reference's unit of work: restorator.js:198-211) go through the engine's batcher: queue NOW,
+        // on the JS thread, so that every in-flight promise is in the queue before any pool thread blocks in ire_poll
+        const int rc = g.submit(j->eng, j->in.data(), j->h, j->w, j->jpeg[0], j->has_scores ? j->scores.data() : nullptr, &j->queued);
+        if (rc != 0) {
+            napi_value msg, err, code;
+            napi_create_string_utf8(env, g.last_error(), NAPI_AUTO_LENGTH, &msg);
+            napi_create_error(env, nullptr, msg, &err);
+            const char* codes[] = {"", "ENGINE_INVALID_INPUT", "ENGINE_TIMEOUT", "ENGINE_UNAVAILABLE", "ENGINE_INTERNAL"};
+            napi_create_string_utf8(env, codes[rc >= 1 && rc <= 4 ? rc : 4], NAPI_AUTO_LENGTH, &code);
+            napi_set_named_property(env, err, "code", code);
+            napi_reject_deferred(env, j->deferred, err);
+            delete j;
+            return promise;
+        }
+        std::vector<uint8_t>().swap(j->in);     // the engine copied it
+    }
     napi_value name;
     napi_create_string_utf8(env, "ire", NAPI_AUTO_LENGTH, &name);
     napi_create_async_work(env, nullptr, name, execute, complete, j, &j->work);
@@ -169,6 +229,91 @@ napi_value submit(napi_env env, napi_callback_info info, Job::Kind kind) {
 napi_value classify_async(napi_env e, napi_callback_info i) { return submit(e, i, Job::CLASSIFY); }
 napi_value restore_async(napi_env e, napi_callback_info i) { return submit(e, i, Job::RESTORE); }
 napi_value fuse_async(napi_env e, napi_callback_info i) { return submit(e, i, Job::FUSE); }
+
+// preprocessPlan(width, height, orientation, maxDim) -> {width, height, resized}   (imagePreprocess.js:12-22,46-55; host arithmetic)
+napi_value preprocess_plan_sync(napi_env env, napi_callback_info info) {
+    size_t argc = 4; napi_value argv[4];
+    napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+    if (argc < 2 || !g.preprocess_plan) { throw_err(env, "invalid arguments (or engine library not loaded: call init first)"); return nullptr; }
+    int ow = 0, oh = 0, rs = 0;
+    const int rc = g.preprocess_plan((int)get_i64(env, argv[0]), (int)get_i64(env, argv[1]), argc > 2 ? (int)get_i64(env, argv[2]) : 1,
+                                     argc > 3 ? (int)get_i64(env, argv[3]) : 2048, &ow, &oh, &rs);
+    if (rc != 0) { throw_err(env, g.last_error()); return nullptr; }
+    napi_value res, v;
+    napi_create_object(env, &res);
+    napi_create_int32(env, ow, &v); napi_set_named_property(env, res, "width", v);
+    napi_create_int32(env, oh, &v); napi_set_named_property(env, res, "height", v);
+    napi_get_boolean(env, rs != 0, &v); napi_set_named_property(env, res, "resized", v);
+    return res;
+}
+
+// preprocessAsync(engine, pixels, h, w, orientation, maxDim) -> Promise<{pixels, width, height, resized}>: EXIF orient + fit-inside
+// Lanczos-3 on the GPU (imagePreprocess.js:43-55); the JPEG q85 encode stays with the host codec
+napi_value preprocess_async(napi_env env, napi_callback_info info) {
+    size_t argc = 6; napi_value argv[6];
+    napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+    if (argc < 4) { throw_err(env, "invalid arguments"); return nullptr; }
+    void* eng = nullptr;
+    if (napi_get_value_external(env, argv[0], &eng) != napi_ok || !eng) { throw_err(env, "invalid engine handle"); return nullptr; }
+    void* data; size_t len; bool is_buf = false;
+    if (napi_is_buffer(env, argv[1], &is_buf) != napi_ok || !is_buf || napi_get_buffer_info(env, argv[1], &data, &len) != napi_ok) {
+        throw_err(env, "invalid input: pixels must be a Buffer");
+        return nullptr;
+    }
+    Job* j = new Job();
+    j->kind = Job::PREPROCESS; j->eng = (ire_engine*)eng; j->n = 1;
+    j->h = (int)get_i64(env, argv[2]); j->w = (int)get_i64(env, argv[3]);
+    j->orientation = argc > 4 ? (int)get_i64(env, argv[4]) : 1;
+    j->max_dim = argc > 5 ? (int)get_i64(env, argv[5]) : 2048;
+    napi_value promise;
+    napi_create_promise(env, &j->deferred, &promise);
+    const size_t need = (size_t)(j->h > 0 ? j->h : 0) * (j->w > 0 ? j->w : 0) * 3;
+    int rc = (need == 0 || len < need) ? 1 : g.preprocess_plan(j->w, j->h, j->orientation, j->max_dim, &j->out_w, &j->out_h, &j->resized);
+    if (rc != 0) {
+        napi_value msg, err;
+        napi_create_string_utf8(env, need == 0 || len < need ? "invalid input: pixel buffer smaller than h*w*3" : g.last_error(), NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, nullptr, msg, &err);
+        napi_reject_deferred(env, j->deferred, err);
+        delete j;
+        return promise;
+    }
+    j->in.assign((uint8_t*)data, (uint8_t*)data + need);
+    napi_value name;
+    napi_create_string_utf8(env, "ire", NAPI_AUTO_LENGTH, &name);
+    napi_create_async_work(env, nullptr, name, execute, complete, j, &j->work);
+    napi_queue_async_work(env, j->work);
+    return promise;
+}
+
+// stats(engine) -> {queueDepth, batches, images, lastBatch, maxBatch, imagesPerSec}   (f4: health entry + images/sec gauge)
+napi_value stats_sync(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1];
+    napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+    void* eng = nullptr;
+    if (argc < 1 || napi_get_value_external(env, argv[0], &eng) != napi_ok || !eng) { throw_err(env, "invalid engine handle"); return nullptr; }
+    ire_engine_stats st; std::memset(&st, 0, sizeof(st)); st.struct_size = sizeof(st);
+    if (g.get_stats((ire_engine*)eng, &st) != 0) { throw_err(env, g.last_error()); return nullptr; }
+    napi_value res, v;
+    napi_create_object(env, &res);
+    napi_create_int32(env, st.queue_depth, &v); napi_set_named_property(env, res, "queueDepth", v);
+    napi_create_int64(env, st.batches, &v); napi_set_named_property(env, res, "batches", v);
+    napi_create_int64(env, st.images, &v); napi_set_named_property(env, res, "images", v);
+    napi_create_int32(env, st.last_batch, &v); napi_set_named_property(env, res, "lastBatch", v);
+    napi_create_int32(env, st.max_batch, &v); napi_set_named_property(env, res, "maxBatch", v);
+    napi_create_double(env, st.images_per_sec, &v); napi_set_named_property(env, res, "imagesPerSec", v);
+    return res;
+}
+
+// maxBatchFor(engine, h, w) -> images of that shape one call can take right now (0: unsupported / out of memory)
+napi_value max_batch_for_sync(napi_env env, napi_callback_info info) {
+    size_t argc = 3; napi_value argv[3];
+    napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+    void* eng = nullptr;
+    if (argc < 3 || napi_get_value_external(env, argv[0], &eng) != napi_ok || !eng) { throw_err(env, "invalid engine handle"); return nullptr; }
+    napi_value v;
+    napi_create_int32(env, g.max_batch_for((ire_engine*)eng, (int)get_i64(env, argv[1]), (int)get_i64(env, argv[2])), &v);
+    return v;
+}
 
 void finalize_engine(napi_env, void* data, void*) { if (data && g.shutdown) g.shutdown((ire_engine*)data); }
 
@@ -201,8 +346,12 @@ napi_value module_init(napi_env env, napi_value exports) {
         {"classifyAsync", nullptr, classify_async, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"restoreAsync", nullptr, restore_async, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"fuseAsync", nullptr, fuse_async, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"preprocessPlan", nullptr, preprocess_plan_sync, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"preprocessAsync", nullptr, preprocess_async, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"stats", nullptr, stats_sync, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"maxBatchFor", nullptr, max_batch_for_sync, nullptr, nullptr, nullptr, napi_default, nullptr},
     };
-    napi_define_properties(env, exports, 4, d);
+    napi_define_properties(env, exports, sizeof(d) / sizeof(d[0]), d);
     return exports;
 }
 

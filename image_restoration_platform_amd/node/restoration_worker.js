@@ -45,7 +45,7 @@ function toBuffer(image) {
 }
 
 // job.data: { userId, gcs_ref | image, user_prompt, traceparent, tracestate } (design.md:195-199, 820-833)
-// deps: restorator {restore(buffer, prompt, ctx)}; loadImage(gcs_ref, job) -> Buffer; storeResult(job, Buffer) -> {gcsResultPath, signedResultUrl};
+// deps: restorator = the reference's RestoratorService (restore({imageBuffer, userPrompt, userContext, options}), restorator.js:37); loadImage(gcs_ref, job) -> Buffer; storeResult(job, Buffer) -> {gcsResultPath, signedResultUrl};
 //       jobStore {update(jobId, patch)} (the jobs/{jobId} document, design.md:642-665); UnrecoverableError (bullmq's, optional)
 function createJobProcessor(deps) {
   const restorator = deps.restorator;
@@ -68,7 +68,13 @@ function createJobProcessor(deps) {
     if (!buffer) throw unrecoverable(deps, fail('invalid job payload: neither image nor gcs_ref', 'INVALID_INPUT', 'INVALID_INPUT'));
 
     // restore() never rejects (restorator.js:37-172): failures come back in the envelope
-    const result = await restorator.restore(buffer, data.user_prompt, { userId: data.userId, jobId: job.id, traceparent: trace.traceparent, tracestate: trace.tracestate });
+    // ONE object argument, exactly the reference's signature (restorator.js:37): restore({ imageBuffer, userPrompt, userContext, options })
+    const result = await restorator.restore({
+      imageBuffer: buffer,
+      userPrompt: data.user_prompt,
+      userContext: { userId: data.userId, jobId: job.id, traceparent: trace.traceparent, tracestate: trace.tracestate },
+      options: {},
+    });
     if (!result || result.success !== true) {
       const e = (result && result.error) || {};
       const err = fail(e.message || 'restoration failed', e.code || 'RESTORATION_FAILED', e.type || 'UNKNOWN_ERROR');

@@ -61,7 +61,9 @@ async function restoreLikeReference(classifier, restorer, imageBuffer) {
     // the queue worker (restoration_worker.js) over the same two seams: one job through a RestoratorService-shaped object
     const wk = require('./restoration_worker.js');
     const updates = [];
-    const restorator = { restore: async (buf) => {
+    const restorator = { restore: async ({ imageBuffer, userPrompt, userContext, options = {} }) => {   // restorator.js:37
+      const buf = imageBuffer;
+      if (typeof buf.length !== 'number') throw new Error('imageBuffer missing');                       // restorator.js:43
       const e = await restoreLikeReference(classifier, restorer, buf);
       return e.success ? Object.assign(e, { enhancedPrompt: 'p', timings: Object.assign({ prompt_ms: 0, total_ms: 1 }, e.timings) })
                        : { success: false, error: { message: e.error.message, code: e.error.code, type: /invalid|unsupported/i.test(e.error.message) ? 'INVALID_INPUT' : 'UNKNOWN_ERROR' }, timings: e.timings, metadata: { failureStage: 'CLASSIFICATION' } };
@@ -71,6 +73,29 @@ async function restoreLikeReference(classifier, restorer, imageBuffer) {
     let err = null;
     try { await processor({ id: 'w2', attemptsMade: 0, data: { userId: 'u', image: Buffer.from('junk').toString('base64') } }); } catch (e) { err = { message: e.message, unrecoverable: !!e.unrecoverable, type: e.type }; }
     out.worker = { good, err, updates };
+  }
+  if (spec.concurrent) {
+    // 8 in-flight single-image jobs (the reference keeps 3 per batch / 5 per worker in flight, restorator.js:14, design.md:851)
+    // must share engine batches: ire_submit on the JS thread, ire_poll on the pool -- counted by the engine itself
+    const hl = ad.createEngineHealth({ engine });
+    const img8 = fs.readFileSync(spec.image8);                                         // H, W multiples of 8: no padding, classified inside
+    const single = await restorer.restoreImage({ prompt: 'p', images: [Buffer.from(img8)] });
+    const before = hl.metrics();
+    const bufs = Array.from({ length: spec.concurrent }, () => Buffer.from(img8));    // distinct Buffer objects
+    const t0 = Date.now();
+    const rs = await Promise.all(bufs.map((b) => restorer.restoreImage({ prompt: 'p', images: [b] })));
+    const ms = Date.now() - t0;
+    const after = hl.metrics();
+    out.concurrent = { batches: after.batches - before.batches, images: after.images - before.images, lastBatch: after.lastBatch, ms: ms,
+                       allEqual: rs.every((x) => x.base64Image === rs[0].base64Image), sameAsSingle: rs[0].base64Image === single.base64Image,
+                       imagesPerSec: after.imagesPerSec, health: await hl.checkEngine() };
+    // decode + classify once per job: analyze() then restoreImage() on the SAME Buffer adds no classifier-only call
+    const b2 = Buffer.from(img);
+    const s0 = hl.metrics();
+    const an = await classifier.analyze(b2);
+    const rr = await restorer.restoreImage({ prompt: 'p', images: [b2] });
+    out.once = { scoresEqual: JSON.stringify(an) === JSON.stringify(out.scores), pixelsEqual: rr.base64Image === r.restoredImage, cached: engine.seen.has(b2),
+                 batches: hl.metrics().batches - s0.batches };
   }
   if (spec.fuse) {
     const views = spec.fuse.map((f) => fs.readFileSync(f));

@@ -26,7 +26,12 @@ class FakeWorker {
 function harness(script) {                           // script: array of restore() envelopes, consumed one per attempt
   const log = { updates: [], dlq: [], refunds: [], stored: [], calls: [] };
   let i = 0;
-  const restorator = { restore: async (buf, prompt, ctx) => { log.calls.push({ bytes: buf.length, prompt: prompt, ctx: ctx }); return script[Math.min(i++, script.length - 1)]; } };
+  // destructures ONE object exactly as restorator.js:37 does, and touches imageBuffer.length as restorator.js:43 does (a positional
+  // call would throw here, as it would in the reference class)
+  const restorator = { restore: async ({ imageBuffer, userPrompt, userContext, options = {} }) => {
+    log.calls.push({ bytes: imageBuffer.length, prompt: userPrompt, ctx: userContext, options: options });
+    return script[Math.min(i++, script.length - 1)];
+  } };
   const deps = {
     Worker: FakeWorker, UnrecoverableError: UnrecoverableError, connection: {}, restorator: restorator, rng: () => 0.5,
     now: () => 'T',

@@ -18,6 +18,7 @@ import base64
 import concurrent.futures
 import io
 import os
+import threading
 import time
 import uuid
 from datetime import datetime, timezone
@@ -64,6 +65,35 @@ def pad_to_multiple(rgb, m=8, min_size=16):
     return np.ascontiguousarray(np.pad(rgb, ((0, H - h), (0, W - w), (0, 0)), mode="edge")), (h, w)
 
 
+class _Seen:
+    """What analyze() learnt about a buffer, for the restoreImage() that follows on the SAME object
+    (restorator.js:59-94 hands one Buffer to both seams): decoded pixels + the 7 scores, so a job is
+    decoded once and classified once.  Keyed by object identity; the entry holds the buffer, which
+    keeps the id valid; a handful of entries (in-flight jobs: 3 per batch, 5 per worker)."""
+
+    def __init__(self, capacity=16):
+        self._d = {}
+        self._cap = capacity
+        self._lock = threading.Lock()
+
+    def put(self, buf, rgb, fmt, scores):
+        with self._lock:
+            if len(self._d) >= self._cap:
+                self._d.pop(next(iter(self._d)))
+            self._d[id(buf)] = (buf, rgb, fmt, scores)
+
+    def take(self, buf):
+        with self._lock:
+            hit = self._d.pop(id(buf), None)
+        return None if hit is None or hit[0] is not buf else hit[1:]
+
+
+def _seen_of(engine):
+    if getattr(engine, "_seen", None) is None:
+        engine._seen = _Seen()
+    return engine._seen
+
+
 class EngineClassifier:
     """classifier seam: analyze(imageBuffer) -> {blur, noise, lowLight, compression, scratch, fade, colorShift}."""
 
@@ -74,6 +104,7 @@ class EngineClassifier:
     def analyze(self, image_buffer):
         rgb, fmt = decode_image(image_buffer)
         scores, _ = self.engine.classify(rgb, is_jpeg=(fmt == "jpeg"))
+        _seen_of(self.engine).put(image_buffer, rgb, fmt, scores[0].copy())
         return {k: float(scores[0, i]) for i, k in enumerate(KEYS)}
 
 
@@ -87,14 +118,26 @@ class EngineRestorer:
     def restore_image(self, prompt, images, user_context=None):
         if not images or len(images) > 3:
             raise ValueError("invalid images: expected 1..3 encoded images")  # provider limit: report.md:28
-        decoded = [decode_image(b) for b in images]
+        seen = _seen_of(self.engine)
+        decoded = []
+        for b in images:             # analyze() already decoded and classified this buffer: reuse both
+            hit = seen.take(b)
+            decoded.append(hit if hit is not None else (*decode_image(b), None))
         shapes = {d[0].shape for d in decoded}
         if len(shapes) != 1:
             raise ValueError("invalid images: fusion views must have identical dimensions")
-        restored = []
-        for rgb, fmt in decoded:
+        # every view goes to the engine's batcher (ire_submit) before the first ire_poll: the views of this call and the
+        # single-image jobs of the other in-flight calls (restore_batch keeps 3 in flight) coalesce into engine batches
+        jobs = []
+        for rgb, fmt, scores in decoded:
             padded, (h, w) = pad_to_multiple(rgb)
-            out = self.engine.restore(padded, scores=None, is_jpeg=(fmt == "jpeg"))[0]
+            if scores is None and padded.shape != rgb.shape:
+                # condition on the image's own scores (what analyze() reports), never on its replicate-padded copy's
+                scores = self.engine.classify(rgb, is_jpeg=(fmt == "jpeg"))[0][0]
+            jobs.append((self.engine.submit(padded, is_jpeg=(fmt == "jpeg"), scores=scores), h, w))
+        restored = []
+        for job, h, w in jobs:
+            out, _, _ = self.engine.poll(job)
             restored.append(np.ascontiguousarray(out[:h, :w]))
         if len(restored) == 1:
             result = restored[0]
@@ -225,17 +268,21 @@ class RestoratorService:
                 ok = True
             except Exception:  # noqa: BLE001
                 ok = False
-            engine_ok = False
+            engine_ok, metrics = False, None
             try:
                 eng = getattr(self.classifier, "engine", None)
                 if eng is not None:
                     eng.classify(np.zeros((16, 16, 3), np.uint8))
                     engine_ok = True
+                    metrics = eng.stats()            # images/sec gauge + batch counters
             except Exception:  # noqa: BLE001
                 engine_ok = False
-            return {"healthy": ok, "services": {"classifier": ok, "promptEnhancer": True, "geminiClient": True,
-                                                "engine": engine_ok},
-                    "timestamp": datetime.now(timezone.utc).isoformat()}
+            out = {"healthy": ok, "services": {"classifier": ok, "promptEnhancer": True, "geminiClient": True,
+                                               "engine": engine_ok},
+                   "timestamp": datetime.now(timezone.utc).isoformat()}
+            if metrics is not None:
+                out["metrics"] = {"engine": metrics}
+            return out
         except Exception as e:  # noqa: BLE001
             return {"healthy": False, "error": str(e), "timestamp": datetime.now(timezone.utc).isoformat()}
 

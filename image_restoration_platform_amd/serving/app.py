@@ -56,7 +56,11 @@ def ready():
     except Exception as e:  # noqa: BLE001
         return JSONResponse(status_code=503, content={"ok": False, "engine": False, "detail": str(e)})
     st = svc.get_health_status()
-    return {"ok": bool(st["services"].get("engine")), **st}
+    ok = bool(st["services"].get("engine"))
+    # the shape of the Node side's GET /health/ready (healthRouter.js:80-117): status + dependencies + metrics
+    dep = {"status": "ok" if ok else "unavailable", "device": "gfx950", **(st.get("metrics", {}).get("engine") or {})}
+    body = {"ok": ok, "status": "ok" if ok else "unready", "dependencies": {"engine": dep}, **st}
+    return body if ok else JSONResponse(status_code=503, content=body)
 
 
 @app.post("/restore")

@@ -26,13 +26,15 @@ def fusion_groups(world, k=3):
 
 
 def timed_region(step, steps, sync, slow=0.0):
-    """bench.py's contract: barrier + sync on both sides, K steps, MAX over ranks."""
+    """bench.py's contract: barrier + sync on both sides, K steps, MAX over ranks.  step(i) if it takes an argument."""
+    import inspect
+    takes_i = len(inspect.signature(step).parameters) >= 1
     if dist.is_initialized():
         dist.barrier()
     sync()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
+    for i in range(steps):
+        step(i) if takes_i else step()
         if slow:
             time.sleep(slow)
     sync()
@@ -68,3 +70,18 @@ def gather_views(view, dst, group_ranks):
         return views
     dist.send(view.contiguous(), dst=dst)
     return None
+
+
+def restore_views_and_fuse(view, group_ranks, dst, restore, fuse):
+    """cfg 3 (geminiClient.js:32,49 = restoreImage with 2..3 images): every rank of the group restores
+    ITS view, the restored views travel to `dst` point-to-point (gather_views), `dst` aligns and blends them.
+    restore(view) -> restored view (same shape/dtype), fuse(list of views in group order) -> fused image.
+    Returns the fused image on dst, None on the other ranks (and on ranks outside the group, which keep doing
+    single-image work)."""
+    if dist.get_rank() not in group_ranks:
+        return None
+    restored = restore(view)
+    views = gather_views(restored, dst, group_ranks)
+    if views is None:
+        return None
+    return fuse(views)

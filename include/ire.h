@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define IRE_ABI_VERSION 1
+#define IRE_ABI_VERSION 2
 
 typedef enum ire_status {
     IRE_OK = 0,
@@ -67,10 +67,10 @@ typedef struct ire_config {
                                  (default 0 = engine's choice)                           */
     const char* weights_path; /* RestoreNet-v0 weight file (DESIGN.md "weight file");
                                  NULL: classify/fuse only until ire_load_weights         */
-    uint32_t flags;           /* IRE_FLAG_*                                              */
+    uint32_t flags;           /* reserved, must be 0                                     */
 } ire_config;
 
-#define IRE_FLAG_NO_GRAPH 1u /* launch kernels eagerly instead of replaying hipGraphs */
+
 
 typedef struct ire_timings { /* GPU time measured with HIP events on the engine's stream; mirrors
                                 timings.classify_ms / restore_ms of restorator.js:48-98         */
@@ -87,7 +87,9 @@ void ire_shutdown(ire_engine* e);
 const char* ire_last_error(void);
 /* Load RestoreNet-v0 weights from memory (same bytes as the weight file). */
 int ire_load_weights(ire_engine* e, const void* blob, size_t bytes);
-/* Images (N*H*W*3 u8 + activations) the engine can hold for this shape; 0 if unsupported. */
+/* Images of this shape one restore call can take right now: min(max_batch, what the free HBM (hipMemGetInfo) holds
+ * at the engine's real per-image footprint: activation workspace + staging); 0 if the shape is unsupported or not
+ * even one image fits (a restore call would then fail with IRE_ERR_UNAVAILABLE "out of device memory"). */
 int ire_max_batch_for(ire_engine* e, int h, int w);
 
 /* ---- host-buffer entry points (synchronous; copy in, run, copy out) -------------------- */
@@ -132,13 +134,26 @@ int ire_preprocess_device(ire_engine* e, const uint8_t* d_rgb, int h, int w, int
 /* ---- async batcher (restoreBatch's in-flight promises) ---------------------------------- */
 typedef struct ire_job ire_job;
 /* Queue one h x w image for restoration; jobs of equal shape are coalesced into batches of up
- * to max_batch.  The input is copied before return. */
-int ire_submit(ire_engine* e, const uint8_t* rgb, int h, int w, int is_jpeg, ire_job** job_out);
+ * to max_batch.  The input is copied before return.  scores: the 7 doubles a previous ire_classify
+ * of this image returned (the job is then not classified again), or NULL => classify inside. */
+int ire_submit(ire_engine* e, const uint8_t* rgb, int h, int w, int is_jpeg, const double* scores, ire_job** job_out);
 /* Wait up to timeout_ms (<0: forever) for the job; on IRE_OK out_rgb (h*w*3), scores_out (7, may
  * be NULL) and t (may be NULL) are filled and the job is released.  IRE_ERR_TIMEOUT leaves the
  * job pending. */
 int ire_poll(ire_engine* e, ire_job* job, int timeout_ms, uint8_t* out_rgb, double* scores_out,
              ire_timings* t);
+
+/* ---- service gauges (getHealthStatus + /health/ready dependency entry: restorator.js:289-314, healthRouter.js:80-117) ---- */
+typedef struct ire_engine_stats {
+    uint32_t struct_size;   /* = sizeof(ire_engine_stats) */
+    int32_t queue_depth;    /* jobs waiting in the batcher */
+    int64_t batches;        /* engine batches (restore calls) since ire_init */
+    int64_t images;         /* images restored since ire_init */
+    int32_t last_batch;     /* images in the most recent batch: > 1 shows in-flight jobs being coalesced */
+    int32_t max_batch;
+    double images_per_sec;  /* gauge: images restored over the last 10 s window / its span (0 when idle) */
+} ire_engine_stats;
+int ire_get_stats(ire_engine* e, ire_engine_stats* out);
 
 /* ---- measurement / diagnostics (used by bench.py and tests; not part of the job path) --- */
 /* Raw integer accumulators of the classifier scan for n images (14 u64 each, order documented in

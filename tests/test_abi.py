@@ -26,7 +26,8 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in _declared():
         assert hasattr(lib, name), name
-    assert _lib.load().ire_abi_version() == 1
+    hdr = int(re.search(r"#define IRE_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "ire.h")).read()).group(1))
+    assert _lib.load().ire_abi_version() == hdr == 2
 
 
 def test_no_cpu_fallback_without_device():

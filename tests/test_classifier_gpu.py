@@ -51,6 +51,10 @@ def test_known_answers_and_golden(engine):
         d = dict(zip(oc.KEYS, s[0]))
         for k, v in c.get("expect", {}).items():
             assert d[k] == pytest.approx(v, abs=1e-12), (c["name"], k)
+        for k, v in c.get("expect_min", {}).items():       # e.g. noisy_seed1234: noise >= ...
+            assert d[k] >= v, (c["name"], k, d[k])
+        for k, v in c.get("expect_max", {}).items():
+            assert d[k] <= v, (c["name"], k, d[k])
         if "label" in c:
             assert oc.KEYS[l[0]] == c["label"]
     for c in json.load(open(os.path.join(HERE, "golden", "classifier_golden.json"))):
@@ -58,6 +62,22 @@ def test_known_answers_and_golden(engine):
         s, l = engine.classify(img, is_jpeg=bool(c["is_jpeg"]))
         assert [float(x).hex() for x in s[0]] == c["scores_hex"], c["index"]
         assert l[0] == c["label"]
+
+
+def test_reference_fixtures_through_jpeg_round_trips(engine):
+    """classifierService.test.js:19-57 on the GPU: the five fixtures rebuilt through real JPEG round trips
+    (tests/ref_fixtures.py <- imageFixtures.js:5-45), the reference's inequalities on the engine's scores, and bit-exact
+    agreement with the oracle on those pixels."""
+    import sys
+    sys.path.insert(0, HERE)
+    import ref_fixtures as rf
+    imgs = []
+    for name, build, check in rf.CASES:
+        img = build()
+        s, _ = engine.classify(img, is_jpeg=True)
+        assert check(dict(zip(oc.KEYS, (float(x) for x in s[0])))), (name, s[0])
+        imgs.append(img)
+    _check(engine, np.stack(imgs), True)
 
 
 def test_extreme_pixels(engine):

@@ -62,3 +62,59 @@ def test_two_rank_gloo_sharding_and_timing():
     assert dt0 == pytest.approx(dt1) and dt0 >= 3 * 0.02        # MAX over ranks: the slow rank sets the time
     assert tot0 == tot1 == float(sum(i * i for i in range(11)))
     assert v0 == [1, 2] and v1 is None
+
+
+def test_bench_starts_its_own_ranks_and_reports_n_gpus(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must start 2 ranks itself (fresh processes) and rank 0 must
+    print ONE JSON line with n_gpus == 2.  --stub swaps the GPU step for a sleep and RCCL for gloo; the launch, sharding
+    (shard_range), timing (timed_region: barrier, K steps, barrier, MAX over ranks) and reporting code are bench.py's own."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--stub", "--batch", "8"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]      # (gloo itself prints a "[Gloo] Rank 0 is connected" line)
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 4 and j["warmup"] == 1 and j["scaling"] == "weak"
+    assert j["config"]["shard_of_rank0"] == [0, 8] and j["config"]["global_batch"] == 16
+    # MAX over ranks: rank 1 sleeps 4 ms per step, rank 0 2 ms
+    assert j["ms_per_step"] >= 4.0 and j["value"] == pytest.approx(2 * 4 * 8 / (j["ms_per_step"] * 4 / 1e3))
+    # as a rank under a launcher (WORLD_SIZE set) it does not spawn: a world of 1 reports n_gpus 1
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "0", "--stub"],
+                        capture_output=True, text=True, timeout=300, env=env)
+    assert r1.returncode == 0 and json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
+
+
+def _fusion_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        from oracle import fusion as ofus          # the CPU oracle is the checker here, never on the product path
+        from image_restoration_platform_amd import synth
+        views = synth.fusion_views(64, 64, seed=5)
+        restore = lambda v: 255 - v                 # stand-in for the per-rank RestoreNet call (any per-view map)
+        fuse = lambda vs: torch.from_numpy(ofus.fuse(np.stack([x.numpy() for x in vs], 0), 0.2)[0])
+        group = [0, 1, 2]
+        fused = sharding.restore_views_and_fuse(torch.from_numpy(views[rank].copy()), group, 0, restore, fuse)
+        single = fuse([restore(torch.from_numpy(views[i].copy())) for i in range(3)]) if rank == 0 else None
+        q.put((rank, None if fused is None else bool(torch.equal(fused, single)), None if fused is None else tuple(fused.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cfg3_restore_on_three_ranks_gather_fuse_equals_single_process():
+    """cfg 3 flow (restore one view per rank -> gather_views -> fuse on dst): fused bytes == the single-process result."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_fusion_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(3))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0] == (0, True, (64, 64, 3)) and res[1][1] is None and res[2][1] is None

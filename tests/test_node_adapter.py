@@ -53,18 +53,25 @@ def test_node_seams_match_python_host(engine, tmp_path):
         p = tmp_path / f"v{i}.raw"
         p.write_bytes(_raw(v))
         vf.append(str(p))
-    out = _run(tmp_path, {"weights": weights.ensure_default(0), "image": str(f), "fuse": vf, "worker": True})
+    f8 = tmp_path / "a8.raw"
+    f8.write_bytes(_raw(synth.image(2, 72, 104)))
+    out = _run(tmp_path, {"weights": weights.ensure_default(0), "image": str(f), "image8": str(f8), "fuse": vf, "worker": True, "concurrent": 8})
     assert out["engine"] is True and out["allEqual"] is True and out["success"] is True
     scores, _ = engine.classify(img, is_jpeg=True)
     from image_restoration_platform_amd.prompt_enhancer import KEYS
     assert [out["scores"][k] for k in KEYS] == [float(x) for x in scores[0]]          # bit-exact through JSON
     padded = np.pad(img, ((0, 2), (0, 3), (0, 0)), mode="edge")
-    ref = engine.restore(padded, scores=None, is_jpeg=True)[0][:70, :101]
+    ref = engine.restore(padded, scores=scores, is_jpeg=True)[0][:70, :101]       # conditioned on the image's own scores, not the padded copy's
     assert out["restoredSha"] == hashlib.sha256(np.ascontiguousarray(ref).tobytes()).hexdigest()
     assert out["metadata"]["estimatedCostUsd"] == 0 and out["metadata"]["billedTokens"] is None
     assert out["metadata"]["providerRequestId"].startswith("ire-")
     assert out["bad"]["success"] is False and out["bad"]["error"]["code"] == "RESTORATION_FAILED"
     assert out["fusedLen"] == 9 + 64 * 64 * 3
+    # 8 concurrent Node jobs are served by the engine's batcher in shared batches (engine-side counters), with identical pixels
+    cc = out["concurrent"]
+    assert cc["images"] == 8 and cc["batches"] <= 2 and cc["allEqual"] and cc["sameAsSingle"], cc
+    assert cc["health"]["ok"] is True and cc["health"]["info"]["status"] == "ok" and cc["health"]["info"]["imagesPerSec"] > 0
+    assert out["once"] == {"scoresEqual": True, "pixelsEqual": True, "cached": True, "batches": 1}
     wk = out["worker"]                                   # the BullMQ-style worker over the engine-backed seams
     assert wk["good"]["status"] == "succeeded" and wk["good"]["providerRequestId"].startswith("ire-")
     assert wk["err"]["unrecoverable"] is True and wk["err"]["type"] == "INVALID_INPUT"
@@ -88,6 +95,8 @@ def test_queue_worker_contract():
     last = o["firstLog"]["updates"][-1]
     assert last["status"] == "succeeded" and last["costUsd"] == 0 and last["signedResultUrl"].endswith("/j1") and last["prompt"] == "P"
     assert o["firstLog"]["calls"][0]["ctx"]["traceparent"] == "00-aa-bb-01" and o["firstLog"]["calls"][0]["prompt"] == "fix"
+    # ONE object argument {imageBuffer, userPrompt, userContext, options} -- the reference's signature (restorator.js:37)
+    assert o["firstLog"]["calls"][0]["options"] == {} and o["firstLog"]["calls"][0]["bytes"] == 3
     assert o["firstLog"]["stored"] == [6] and o["firstLog"]["dlq"] == [] and o["firstLog"]["refunds"] == []
     # retryable failures go back to queued, with the jittered-exponential delays, then succeed; gcs_ref goes through loadImage
     assert [u["status"] for u in o["retryLog"]["updates"]] == ["running", "queued", "running", "queued", "running", "succeeded"]

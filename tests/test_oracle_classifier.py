@@ -10,6 +10,8 @@ from image_restoration_platform_amd import synth
 from oracle import classifier as oc
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+import sys  # noqa: E402
+sys.path.insert(0, HERE)
 KEYS = oc.KEYS
 
 
@@ -49,6 +51,22 @@ def test_reference_inequality_tests():
     assert oc.classify(cast)[0][6] > 0.25                      # colorShift > 0.25
     s = oc.classify(flat)[0]
     assert np.all(s >= 0) and np.all(s <= 1)                   # clean: all in [0,1]
+
+
+def test_reference_inequality_tests_through_jpeg_round_trips():
+    """The same five assertions on fixtures built the way imageFixtures.js:5-45 builds them: real JPEG encodes (q95;
+    blur(4) + q60; seeded noise q80) decoded again (tests/ref_fixtures.py; PIL's codec stands in for sharp's)."""
+    import ref_fixtures as rf
+    for name, build, check in rf.CASES:
+        img = build()
+        assert img.shape == (128, 128, 3)
+        s, _ = oc.classify(img, True)                         # metadata.format === 'jpeg'
+        assert check(dict(zip(KEYS, (float(x) for x in s)))), (name, s)
+    # the JPEG round trip leaves the flat fixtures flat to +-1 LSB, so the analytic answers still hold to 1e-2
+    d = dict(zip(KEYS, oc.classify(rf.dark(), True)[0]))
+    assert d["lowLight"] == pytest.approx((0.3 - 10 / 255) * 2, abs=1e-2) and d["blur"] == pytest.approx(1.0, abs=1e-2)
+    d = dict(zip(KEYS, oc.classify(rf.color_shifted(), True)[0]))
+    assert d["colorShift"] == 1.0
 
 
 def test_twopass_js_order_agrees_with_integer_form():
