@@ -24,6 +24,11 @@ class IreEngineStats(ctypes.Structure):
                 ("images_per_sec", ctypes.c_double)]
 
 
+class IreStripXchg(ctypes.Structure):
+    _fields_ = [("halo_bytes", ctypes.c_int32), ("has_up", ctypes.c_int32), ("has_down", ctypes.c_int32),
+                ("stats_offset_bytes", ctypes.c_int64), ("stats_local_bytes", ctypes.c_int64), ("stats_total_bytes", ctypes.c_int64)]
+
+
 # every symbol include/ire.h declares: (name, restype, argtypes)
 _vp, _i, _u8p = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
 SYMBOLS = {
@@ -43,6 +48,16 @@ SYMBOLS = {
     "ire_preprocess": (_i, [_vp, _u8p, _i, _i, _i, _i, _u8p, _i, _i]),
     "ire_preprocess_device": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "ire_submit": (_i, [_vp, _u8p, _i, _i, _i, _vp, ctypes.POINTER(_vp)]),
+    "ire_restore_tiled_device": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ire_strips_stats_bytes": (ctypes.c_size_t, [_i, _i]),
+    "ire_strips_open": (_i, [_vp, _i, _i, _i, _i, _i, _vp, ctypes.POINTER(_vp)]),
+    "ire_strips_close": (None, [_vp]),
+    "ire_strips_num_ops": (_i, [_vp]),
+    "ire_strips_set_input": (_i, [_vp, _vp, _vp, _vp]),
+    "ire_strips_run_op": (_i, [_vp, _i, _vp, ctypes.POINTER(IreStripXchg)]),
+    "ire_strips_pack_halo": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "ire_strips_unpack_halo": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "ire_strips_get_output": (_i, [_vp, _vp, _vp]),
     "ire_get_stats": (_i, [_vp, ctypes.POINTER(IreEngineStats)]),
     "ire_poll": (_i, [_vp, _vp, _i, _u8p, _vp, ctypes.POINTER(IreTimings)]),
     "ire_debug_classifier_sums": (_i, [_vp, _i, _vp]),

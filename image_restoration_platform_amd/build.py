@@ -28,6 +28,7 @@ SOURCES = [
     ("fusion.hip", []),
     ("preprocess.hip", []),
     ("engine.cpp", []),
+    ("strips.cpp", []),
     ("api.cpp", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

@@ -9,6 +9,7 @@
 
 #include "engine.hpp"
 #include "fusion.hpp"
+#include "strips.hpp"
 
 namespace ire {
 
@@ -30,6 +31,7 @@ struct Job {
 }  // namespace ire
 
 struct ire_job { std::shared_ptr<ire::Job> j; };
+struct ire_strips { std::unique_ptr<ire::StripSession> s; };
 
 struct ire_engine {
     std::unique_ptr<ire::Engine> eng;
@@ -349,6 +351,77 @@ int ire_preprocess_device(ire_engine* e, const uint8_t* d_rgb, int h, int w, int
     return guarded([&] {
         Engine& E = eng(e);
         on_stream(E, (hipStream_t)stream, [&] { E.preprocess_device(d_rgb, h, w, orientation, max_dim, d_out_rgb, out_h, out_w, (hipStream_t)stream); });
+    });
+}
+
+int ire_restore_tiled_device(ire_engine* e, const uint8_t* d_rgb, int h, int w, int nstrips, const double* d_scores,
+                             const uint8_t* d_is_jpeg, uint8_t* d_out_rgb, void* stream) {
+    return guarded([&] {
+        Engine& E = eng(e);
+        on_stream(E, (hipStream_t)stream, [&] { E.restore_tiled_device(d_rgb, h, w, nstrips, d_scores, d_is_jpeg, d_out_rgb, (hipStream_t)stream); });
+    });
+}
+
+size_t ire_strips_stats_bytes(int h, int w) { return (h > 0 && w > 0) ? StripSession::stats_floats(h, w) * 4 : 0; }
+
+int ire_strips_open(ire_engine* e, int h, int w, int nstrips_total, int first_strip, int nlocal, void* d_stats_all, ire_strips** out) {
+    return guarded([&] {
+        Engine& E = eng(e);
+        if (!out) fail(IRE_ERR_INVALID_INPUT, "invalid arguments to ire_strips_open");
+        *out = nullptr;
+        std::lock_guard<std::mutex> lk(E.mutex());
+        std::unique_ptr<ire_strips> S(new ire_strips());
+        S->s.reset(new StripSession(E, h, w, nstrips_total, first_strip, nlocal, (float*)d_stats_all));
+        *out = S.release();
+    });
+}
+
+void ire_strips_close(ire_strips* s) {
+    if (!s) return;
+    if (s->s) { std::lock_guard<std::mutex> lk(s->s->engine().mutex()); s->s.reset(); }
+    delete s;
+}
+
+static StripSession& strips_of(ire_strips* s) {
+    if (!s || !s->s) fail(IRE_ERR_INVALID_INPUT, "invalid strip session handle");
+    return *s->s;
+}
+
+int ire_strips_num_ops(ire_strips* s) { return (s && s->s) ? s->s->num_ops() : 0; }
+
+int ire_strips_set_input(ire_strips* s, const uint8_t* d_rows_with_halo, const double* d_scores, void* stream) {
+    return guarded([&] {
+        StripSession& S = strips_of(s);
+        on_stream(S.engine(), (hipStream_t)stream, [&] { S.set_input(d_rows_with_halo, d_scores, (hipStream_t)stream); });
+    });
+}
+
+int ire_strips_run_op(ire_strips* s, int k, void* stream, ire_strip_xchg* info) {
+    return guarded([&] {
+        StripSession& S = strips_of(s);
+        on_stream(S.engine(), (hipStream_t)stream, [&] { S.run_op(k, (hipStream_t)stream, info); });
+    });
+}
+
+int ire_strips_pack_halo(ire_strips* s, int k, uint8_t* d_send_up, uint8_t* d_send_down, void* stream) {
+    return guarded([&] {
+        StripSession& S = strips_of(s);
+        on_stream(S.engine(), (hipStream_t)stream, [&] { S.pack_halo(k, d_send_up, d_send_down, (hipStream_t)stream); });
+    });
+}
+
+int ire_strips_unpack_halo(ire_strips* s, int k, const uint8_t* d_recv_up, const uint8_t* d_recv_down, void* stream) {
+    return guarded([&] {
+        StripSession& S = strips_of(s);
+        on_stream(S.engine(), (hipStream_t)stream, [&] { S.unpack_halo(k, d_recv_up, d_recv_down, (hipStream_t)stream); });
+    });
+}
+
+int ire_strips_get_output(ire_strips* s, uint8_t* d_out_rows, void* stream) {
+    return guarded([&] {
+        StripSession& S = strips_of(s);
+        if (!d_out_rows) fail(IRE_ERR_INVALID_INPUT, "invalid output pointer");
+        on_stream(S.engine(), (hipStream_t)stream, [&] { S.get_output(d_out_rows, (hipStream_t)stream); });
     });
 }
 

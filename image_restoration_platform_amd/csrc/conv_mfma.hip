@@ -114,7 +114,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(ConvArgs a) {
     const int trem = t - img * tiles_per_img;
     const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
     const int oy0 = ty * TH, ox0 = tx * TW;
-    const int HV = UPS ? a.Hin * 2 : a.Hin, WV = UPS ? a.Win * 2 : a.Win;  // virtual input extent
+    const int WV = UPS ? a.Win * 2 : a.Win;  // virtual input width (rows: a.iy_lo / a.iy_span)
 
     f32x16_t acc[MT][NTL];
 #pragma unroll
@@ -157,11 +157,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(ConvArgs a) {
                 const int p = idx / KC8;
                 const int py = p / IW, px = p - py * IW;
                 const int iy = oy0 * STRIDE + py - C::PAD, ix = ox0 * STRIDE + px - C::PAD;
-                ok[it] = (idx < C::IN_CHUNKS) && iy >= 0 && iy < HV && ix >= 0 && ix < WV;
+                ok[it] = (idx < C::IN_CHUNKS) && (unsigned)(iy - a.iy_lo) < (unsigned)a.iy_span && ix >= 0 && ix < WV;
                 v[it] = make_uint4(0, 0, 0, 0);
                 if (ok[it]) {
                     const int sy = UPS ? (iy >> 1) : iy, sx = UPS ? (ix >> 1) : ix;
-                    const size_t pix = ((size_t)img * a.Hin + sy) * a.Win + sx;
+                    const size_t pix = ((size_t)img * a.in_rows + sy + a.in_row_off) * a.Win + sx;
                     if constexpr (PRO == PRO_U8) {
                         const unsigned char* pb = reinterpret_cast<const unsigned char*>(a.in0) + pix * 3;
                         // u8 -> bf16 is exact (integers <= 255); channels 3..7 are zero padding

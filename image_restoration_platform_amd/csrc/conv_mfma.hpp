@@ -36,6 +36,13 @@ struct ConvArgs {
     int group_size;              // cout / 8
     int stat_slots;              // 0: stats[nimg][tiles][8][2] per tile; > 0 (= grid size): stats[nimg][slots][8][2], one entry per workgroup
     int prio_young;              // conv_rb: raise the issue priority of waves 4-7
+    // Row-strip execution (cfg 4, engine.cpp "strips"): the input tensors of a strip carry `in_row_off` halo rows above local
+    // row 0 (and as many below); a (virtual) input row iy of the strip is readable iff iy_lo <= iy < iy_lo + iy_span -- the
+    // halo row of a neighbouring strip is data, a row outside the image is zero padding.  Whole images: in_rows = Hin,
+    // in_row_off = 0, iy_lo = 0, iy_span = virtual input height.
+    int in_rows;                 // allocated rows per image of in0 / in1
+    int in_row_off;              // buffer row of local row 0
+    int iy_lo, iy_span;
     int w4_waves;                // conv_w4 on a pre-activated input (ab == nullptr): 8 (default) or 4 waves per workgroup
     unsigned long long* stamps;  // diagnostic builds only (IRE_RB_ABLATE, DBG bit 16): s_memtime stamps, else null
 };

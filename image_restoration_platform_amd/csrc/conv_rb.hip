@@ -222,10 +222,10 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         const int kc = si.kc;
         const int oy1 = it.ty * RB_TH - 1, ox1 = it.tx * RB_TW - 1;
         // wave-uniform image base (SGPR pair) + 32-bit per-lane byte offset
-        const char* base = reinterpret_cast<const char*>(src) + (size_t)it.img * a.Hin * a.Win * Cin * 2 + kc * 64;
+        const char* base = reinterpret_cast<const char*>(src) + (size_t)it.img * a.in_rows * a.Win * Cin * 2 + kc * 64;
         // range-checked buffer loads: a halo pixel outside the image gets an offset past num_records and reads as zero --
         // no coordinate clamping (4 min/max per chunk); the `ok` bit still gates the value AFTER the activation
-        const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, a.Hin * a.Win * Cin * 2 - kc * 64, 0x00020000);
+        const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, a.in_rows * a.Win * Cin * 2 - kc * 64, 0x00020000);
         R.ok = 0;
         int t2 = tid;
         asm volatile("" : "+v"(t2));   // recompute the halo coordinates per stage: cheaper than 5 live registers
@@ -235,9 +235,9 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
             const int py = p / RB_IW, px = p - py * RB_IW;
             const int iy = oy1 + py, ix = ox1 + px;
             // UPS: the conv runs on the nearest-x2 upsampled grid (extent = output extent); source pixel = coord >> 1
-            const int HV = UPS ? a.Hout : a.Hin, WV = UPS ? a.Wout : a.Win;
-            const bool ok = (unsigned)iy < (unsigned)HV && (unsigned)ix < (unsigned)WV;   // slots past the tile (py >= 18) land in the LDS padding
-            const int sy = UPS ? (iy >> 1) : iy, sx = UPS ? (ix >> 1) : ix;
+            const int WV = UPS ? a.Wout : a.Win;
+            const bool ok = (unsigned)(iy - a.iy_lo) < (unsigned)a.iy_span && (unsigned)ix < (unsigned)WV;   // slots past the tile (py >= 18) land in the LDS padding
+            const int sy = (UPS ? (iy >> 1) : iy) + a.in_row_off, sx = UPS ? (ix >> 1) : ix;
             const unsigned off = ok ? ((unsigned)(sy * a.Win + sx) << (cin_shift + 1)) + (unsigned)(c8_fixed * 16) : 0xffffffffu;
             if constexpr (DBG & 8) R.v[i] = make_uint4(off, 0x3f803f80u, i, 0x3f803f80u);
             else {

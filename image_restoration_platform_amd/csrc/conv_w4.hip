@@ -142,16 +142,16 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
     auto load_chunk = [&](const StageInfo& si, int i, Regs& R) {
         const W4Item& it = si.it;
         const int oy1 = it.ty * W4_TH - 1, ox1 = it.tx * W4_TW - 1;
-        const char* base = reinterpret_cast<const char*>(a.in0) + (size_t)it.img * a.Hin * a.Win * Cin * 2 + si.kc * 32;
+        const char* base = reinterpret_cast<const char*>(a.in0) + (size_t)it.img * a.in_rows * a.Win * Cin * 2 + si.kc * 32;
         int t2 = tid;
         asm volatile("" : "+v"(t2));
         const int p = (t2 + i * C::THREADS) >> 1;
         const int py = p / W4_IW, px = p - py * W4_IW;
         const int iy = oy1 + py, ix = ox1 + px;
-        const int HV = UPS ? a.Hout : a.Hin, WV = UPS ? a.Wout : a.Win;
-        const int cy = min(max(iy, 0), HV - 1), cx = min(max(ix, 0), WV - 1);
+        const int WV = UPS ? a.Wout : a.Win;
+        const int cy = min(max(iy, a.iy_lo), a.iy_lo + a.iy_span - 1), cx = min(max(ix, 0), WV - 1);
         const bool ok = iy == cy && ix == cx;
-        const int sy = UPS ? (cy >> 1) : cy, sx = UPS ? (cx >> 1) : cx;
+        const int sy = (UPS ? (cy >> 1) : cy) + a.in_row_off, sx = UPS ? (cx >> 1) : cx;
         const unsigned off = ((unsigned)(sy * a.Win + sx) << (cin_shift + 1)) + (unsigned)(c8_fixed * 16);
         R.v[i] = *reinterpret_cast<const u32x4_t*>(base + off);
         R.ok = (R.ok & ~(1u << i)) | (ok ? (1u << i) : 0u);

@@ -11,6 +11,7 @@
 #include <fstream>
 
 #include "gn.hpp"
+#include "strips.hpp"
 #include "grey_tables.inc"
 
 namespace ire {
@@ -124,6 +125,7 @@ Engine::~Engine() {
         (void)hipFree(stamps_dev_);
     }
     free_workspace();
+    delete tiled_;
     for (void* p : net_.allocs) (void)hipFree(p);
     for (void* p : table_allocs_) (void)hipFree(p);
     for (void* p : {(void*)d_in_, (void*)d_out_, (void*)d_jpeg_, (void*)d_sums_, (void*)d_scores_, (void*)d_label_,
@@ -295,6 +297,7 @@ void Engine::load_weights(const void* blob, size_t bytes) {
     }
     IRE_HIP(hipSetDevice(device_));
     IRE_HIP(hipDeviceSynchronize());
+    delete tiled_; tiled_ = nullptr;
     for (void* q : net_.allocs) (void)hipFree(q);
     net_ = Net{};
     net_.stem = make_conv(CONV_STEM, "stem.w", "stem.b", 3, 32);
@@ -327,6 +330,7 @@ void Engine::load_weights(const void* blob, size_t bytes) {
     }
     host_w_.clear();
     net_.loaded = true;
+    build_program();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -512,36 +516,121 @@ void Engine::debug_sums(int n, uint64_t* out) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// RestoreNet-v0 schedule
+// RestoreNet-v0 schedule: a program of ops (built once per weight load), executed op by op
 // ------------------------------------------------------------------------------------------------
-void Engine::launch_conv(Lane& L, const ConvW& cw, const void* in0, const void* in1, const float2* ab,
-                         const unsigned short* resid, unsigned short* out, const uint8_t* u8_in, uint8_t* u8_out,
-                         int nimg, int Hin, int Win, int Hout, int Wout, const char* cap_name) {
+void Engine::build_program() {
+    program_.clear();
+    const bool v2 = rb_tile_h_ == kRbTileH;
+    auto gn = [&](const GNW& g) { Op o; o.kind = Op::GN; o.gn = &g; program_.push_back(o); };
+    auto conv = [&](const ConvW& cw, int in0, int in1, int resid, int out, int lin, int lout, bool use_ab, const std::string& name) {
+        Op o; o.kind = Op::CONV; o.cw = &cw; o.in0 = in0; o.in1 = in1; o.resid = resid; o.out = out; o.lin = lin; o.lout = lout;
+        o.use_ab = use_ab; o.name = name;
+        o.halo_out = cw.kind != CONV_UP && cw.kind != CONV_HEAD;         // `up` feeds the 1x1 fuse only, the head writes pixels
+        o.stats_out = cw.kind != CONV_UP && cw.kind != CONV_HEAD;
+        program_.push_back(o);
+    };
+    auto act = [&](int in0, int out, int l) { Op o; o.kind = Op::ACT; o.in0 = in0; o.out = out; o.lin = o.lout = l; program_.push_back(o); };
+    // ResBlock: out = x + conv2(silu(gn2(conv1(silu(gn1(x)))))); the partials of x were written by x's producer
+    auto resblock = [&](const RBW& rb, int x, int tmp, int out, int l, const std::string& name) {
+        const bool split = v2 && kWidths[l] >= act_split_min_c_;      // activation as its own pass (A/B switch, off by default)
+        const int ab_buf = buf_id(l, 5);
+        gn(rb.gn1);
+        if (split) act(x, ab_buf, l);
+        conv(rb.conv1, split ? ab_buf : x, BUF_NONE, BUF_NONE, tmp, l, l, !split, name + ".h");
+        gn(rb.gn2);
+        if (split) act(tmp, ab_buf, l);     // h is only ever read through GN2+SiLU (capture keeps raw h)
+        conv(rb.conv2, split ? ab_buf : tmp, BUF_NONE, x, out, l, l, !split, name);
+    };
+    conv(net_.stem, BUF_NONE, BUF_NONE, BUF_NONE, buf_id(0, 0), 0, 0, false, "stem");
+    int x = buf_id(0, 0);
+    for (int l = 0; l < 4; ++l) {
+        const int rb1_out = (l < 3) ? buf_id(l, 4) : buf_id(l, 3);
+        resblock(net_.enc[l][0], x, buf_id(l, 1), buf_id(l, 2), l, "enc" + std::to_string(l) + ".rb0");
+        resblock(net_.enc[l][1], buf_id(l, 2), buf_id(l, 1), rb1_out, l, "enc" + std::to_string(l) + ".rb1");
+        if (l < 3) {
+            conv(net_.down[l], rb1_out, BUF_NONE, BUF_NONE, buf_id(l + 1, 0), l, l + 1, false, "down" + std::to_string(l));
+            x = buf_id(l + 1, 0);
+        }
+    }
+    resblock(net_.mid[0], buf_id(3, 3), buf_id(3, 1), buf_id(3, 0), 3, "mid.rb0");
+    resblock(net_.mid[1], buf_id(3, 0), buf_id(3, 1), buf_id(3, 2), 3, "mid.rb1");
+    int deep = buf_id(3, 2);
+    for (int l = 2; l >= 0; --l) {
+        const std::string sl = std::to_string(l);
+        conv(net_.up[l], deep, BUF_NONE, BUF_NONE, buf_id(l, 0), l + 1, l, false, "up" + sl);
+        conv(net_.fuse[l], buf_id(l, 0), buf_id(l, 4), BUF_NONE, buf_id(l, 2), l, l, false, "fuse" + sl);
+        resblock(net_.dec[l][0], buf_id(l, 2), buf_id(l, 1), buf_id(l, 3), l, "dec" + sl + ".rb0");
+        resblock(net_.dec[l][1], buf_id(l, 3), buf_id(l, 1), buf_id(l, 0), l, "dec" + sl + ".rb1");
+        deep = buf_id(l, 0);
+    }
+    gn(net_.head_gn);
+    conv(net_.head, deep, BUF_NONE, BUF_NONE, BUF_NONE, 0, 0, true, "");
+}
+
+Geo Engine::geo_of_lane(const Lane& L, int nimg, int h, int w, const uint8_t* d_in, uint8_t* d_out) {
+    Geo g;
+    g.nimg = nimg; g.h = h; g.w = w; g.H = h;
+    for (int l = 0; l < 4; ++l) {
+        for (int b = 0; b < 4; ++b) g.buf[l][b] = L.act[l][b];
+        g.buf[l][4] = l < 3 ? L.skip[l] : nullptr;
+        g.buf[l][5] = L.actbuf[l];
+    }
+    g.img_in = d_in; g.img_out = d_out;
+    return g;
+}
+
+void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
+    const ConvW& cw = *op.cw;
+    const int Hin = g.h >> op.lin, Win = g.w >> op.lin, Hout = g.h >> op.lout, Wout = g.w >> op.lout;
+    // inputs are addressed from the buffer start (halo row included: in_row_off), outputs / residual from the first real row
+    auto in_ptr = [&](int id) -> const unsigned short* { return id == BUF_NONE ? nullptr : g.buf[id >> 3][id & 7]; };
+    auto out_ptr = [&](int id) -> unsigned short* {
+        if (id == BUF_NONE) return nullptr;
+        const int l = id >> 3;
+        return g.buf[l][id & 7] + (size_t)g.halo * (g.w >> l) * kWidths[l];
+    };
     ConvArgs a{};
-    a.in0 = in0; a.in1 = in1; a.cin0 = cw.cin0; a.cin1 = cw.cin1; a.kc_split = cw.kc_split; a.nkc = cw.nkc;
-    a.w = cw.d_w; a.bias = cw.d_bias; a.ab = ab; a.resid = resid; a.out = out; a.u8_in = u8_in; a.u8_out = u8_out;
-    a.stats = L.stats;
+    a.in0 = (cw.kind == CONV_STEM) ? (const void*)g.img_in : (const void*)in_ptr(op.in0);
+    a.in1 = in_ptr(op.in1);
+    a.cin0 = cw.cin0; a.cin1 = cw.cin1; a.kc_split = cw.kc_split; a.nkc = cw.nkc;
+    a.w = cw.d_w; a.bias = cw.d_bias; a.ab = op.use_ab ? R.ab : nullptr; a.resid = out_ptr(op.resid); a.out = out_ptr(op.out);
+    a.u8_in = cw.kind == CONV_HEAD ? g.img_in + (size_t)g.halo * g.w * 3 : nullptr;
+    a.u8_out = cw.kind == CONV_HEAD ? g.img_out : nullptr;
     a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout;
+    a.in_rows = Hin + 2 * g.halo; a.in_row_off = g.halo;
+    {
+        const int HV = cw.kind == CONV_UP ? 2 * Hin : Hin;      // virtual input rows (nearest x2 folded into the staging)
+        a.iy_lo = (g.halo && g.has_up) ? -1 : 0;
+        a.iy_span = HV + ((g.halo && g.has_down) ? 1 : 0) - a.iy_lo;
+    }
     a.cout = (cw.kind == CONV_HEAD) ? 32 : cw.cout;
     a.tiles_x = ceil_div(Wout, 32);
     const bool rb = (cw.kind == CONV_RB1 || cw.kind == CONV_RB2);
     const bool up_rb = (cw.kind == CONV_UP) && rb_tile_h_ == kRbTileH && cw.cout >= up_rb_min_c_;
-    a.tiles_y = ceil_div(Hout, (rb || up_rb) ? rb_tile_h_ : conv_tile_h(cw.kind));
-    if (up_rb) a.stats = nullptr;
-    a.nimg = nimg; a.nblocks = cw.nblocks;
+    const int th = (rb || up_rb) ? rb_tile_h_ : conv_tile_h(cw.kind);
+    a.tiles_y = ceil_div(Hout, th);
+    a.stats = nullptr;
+    if (op.stats_out) {
+        // partials are indexed by the GLOBAL tile: a strip writes its tiles at its offset (strip starts are multiples of the
+        // tile height at every level: checked by the strip planner), so the finalize sees exactly the whole-image layout
+        const int ty0 = (g.y0 >> op.lout) / th;
+        a.stats = R.stats + (size_t)ty0 * a.tiles_x * 16;
+        R.stat_parts = a.tiles_x * ceil_div(g.H >> op.lout, th);
+    }
+    a.nimg = g.nimg; a.nblocks = cw.nblocks;
     a.group_size = std::max(1, a.cout / 8);
     a.stamps = nullptr;
     a.stat_slots = 0;
     a.prio_young = prio_young_;
-    a.w4_waves = (ab == nullptr) ? w4_waves_ : 8;
+    a.w4_waves = (a.ab == nullptr) ? w4_waves_ : 8;
     if (stamps_dev_ && rb && cw.cout == stamps_cout_ && (cw.kind == CONV_RB2) == stamps_resid_ && !stamps_taken_) {
         a.stamps = stamps_dev_;
         stamps_taken_ = true;
     }
     const int taps = (cw.kind == CONV_FUSE) ? 1 : 9;
-    const double px = (double)nimg * Hout * Wout;
+    const double px = (double)g.nimg * Hout * Wout;
     const double flops = 2.0 * taps * cw.cin * cw.cout * px;
-    const double in_px = (double)nimg * Hin * Win;
+    const double in_px = (double)g.nimg * Hin * Win;
     double bytes = in_px * cw.cin * (cw.kind == CONV_STEM ? 1 : 2) + px * cw.cout * (cw.kind == CONV_HEAD ? 1 : 2);
     if (cw.kind == CONV_RB2) bytes += px * cw.cout * 2;
     if (cw.kind == CONV_HEAD) bytes += px * 3;
@@ -549,101 +638,50 @@ void Engine::launch_conv(Lane& L, const ConvW& cw, const void* in0, const void* 
     if (cw.kind == CONV_FUSE) fam = FAM_CONV1;
     else if (cw.kind == CONV_STEM) fam = FAM_STEM;
     else if (cw.kind == CONV_HEAD) fam = FAM_HEAD;
-    prof_begin(fam, L.stream, flops, bytes);
+    prof_begin(fam, R.stream, flops, bytes);
     // conv_w4: pre-activated input (ab == nullptr) or, from w4_fused_min_c_ up, activation fused into its staging (8-wave form)
-    const bool w4 = rb && rb_tile_h_ == kRbTileH && use_w4_ && cw.d_w4 != nullptr && (ab == nullptr || cw.cout >= w4_fused_min_c_);
-    if (a.stats) L.stat_parts = a.tiles_x * a.tiles_y;
-    if (slot_stats_ && !w4 && !up_rb && rb && rb_tile_h_ == kRbTileH && a.stats) {
-        a.stat_slots = conv_rb_stat_slots(ab != nullptr, a);
-        if (a.stat_slots) L.stat_parts = a.stat_slots;
+    const bool w4 = rb && rb_tile_h_ == kRbTileH && use_w4_ && cw.d_w4 != nullptr && (a.ab == nullptr || cw.cout >= w4_fused_min_c_);
+    if (slot_stats_ && !w4 && !up_rb && rb && rb_tile_h_ == kRbTileH && a.stats && g.halo == 0) {
+        a.stat_slots = conv_rb_stat_slots(a.ab != nullptr, a);
+        if (a.stat_slots) R.stat_parts = a.stat_slots;
     }
     if (w4) {
         a.w = cw.d_w4; a.nkc = cw.cin / 16; a.nblocks = cw.cout / 128;
-        conv_w4_launch(cw.kind == CONV_RB2, a, L.stream);
-    } else if (up_rb) { if (cw.d_wp) a.w = cw.d_wp; conv_up_launch(a, L.stream); }
-    else if (rb && rb_tile_h_ == kRbTileH) { if (cw.d_wp) a.w = cw.d_wp; conv_rb_launch(cw.kind == CONV_RB2, /*fused_act=*/ab != nullptr, a, L.stream); }
-    else conv_launch(cw.kind, a, L.stream);
-    prof_end(L.stream);
-    if (capture_ && cap_name && out) capture(cap_name, out, (size_t)nimg * Hout * Wout * cw.cout, L.stream);
+        conv_w4_launch(cw.kind == CONV_RB2, a, R.stream);
+    } else if (up_rb) { if (cw.d_wp) a.w = cw.d_wp; conv_up_launch(a, R.stream); }
+    else if (rb && rb_tile_h_ == kRbTileH) { if (cw.d_wp) a.w = cw.d_wp; conv_rb_launch(cw.kind == CONV_RB2, /*fused_act=*/a.ab != nullptr, a, R.stream); }
+    else conv_launch(cw.kind, a, R.stream);
+    prof_end(R.stream);
+    if (capture_ && !op.name.empty() && a.out && g.halo == 0) capture(op.name.c_str(), a.out, (size_t)g.nimg * Hout * Wout * cw.cout, R.stream);
 }
 
-void Engine::launch_gn(Lane& L, const GNW& g, int nimg, int Ht, int Wt, int ntiles, const float* d_film) {
-    prof_begin(FAM_GN, L.stream, 0, 0);
-    (void)ntiles;   // the producer recorded how many partials per image it wrote
-    gn_finalize_launch(L.stats, nimg, L.stat_parts, g.C, Ht * Wt, g.d_gamma, g.d_beta, d_film, kFilmDim, kFilmOff[g.level],
-                       L.ab, L.stream);
-    prof_end(L.stream);
+void Engine::exec_op(Run& R, const Op& op, const Geo& g) {
+    switch (op.kind) {
+        case Op::GN: {
+            const GNW& gn = *op.gn;
+            prof_begin(FAM_GN, R.stream, 0, 0);
+            gn_finalize_launch(R.stats, g.nimg, R.stat_parts, gn.C, (g.H >> gn.level) * (g.w >> gn.level), gn.d_gamma, gn.d_beta, R.film, kFilmDim,
+                               kFilmOff[gn.level], R.ab, R.stream);
+            prof_end(R.stream);
+            break;
+        }
+        case Op::ACT: {
+            const int l = op.lin, Ht = g.h >> l, Wt = g.w >> l, C = kWidths[l];
+            if (g.halo) fail(IRE_ERR_INTERNAL, "internal: the separate activation pass is not available in strip mode");
+            prof_begin(FAM_GN, R.stream, 0, 2.0 * g.nimg * Ht * Wt * C * 2);
+            gn_apply_silu_launch(g.buf[op.in0 >> 3][op.in0 & 7], R.ab, g.buf[op.out >> 3][op.out & 7], g.nimg, Ht * Wt, C, R.stream);
+            prof_end(R.stream);
+            break;
+        }
+        case Op::CONV: exec_conv(R, op, g); break;
+    }
 }
 
 void Engine::run_network(Lane& L, int nimg, int h, int w, const uint8_t* d_in, uint8_t* d_out, const float* d_film) {
-    auto tiles = [&](int Ht, int Wt, int th) { return ceil_div(Wt, 32) * ceil_div(Ht, th); };
-    // ResBlock: out = x + conv2(silu(gn2(conv1(silu(gn1(x)))))); stats of x are in L.stats on entry,
-    // stats of out are in L.stats on exit.
-    auto resblock = [&](const RBW& rb, const unsigned short* x, unsigned short* tmp, unsigned short* out, int l,
-                        int x_tiles, const std::string& name) {
-        const int Ht = h >> l, Wt = w >> l, C = kWidths[l];
-        const bool split = (rb_tile_h_ == kRbTileH) && C >= act_split_min_c_;   // activation as its own pass
-        launch_gn(L, rb.gn1, nimg, Ht, Wt, x_tiles, d_film);
-        const unsigned short* in1 = x;
-        if (split) {
-            prof_begin(FAM_GN, L.stream, 0, 2.0 * nimg * Ht * Wt * C * 2);
-            gn_apply_silu_launch(x, L.ab, L.actbuf[l], nimg, Ht * Wt, C, L.stream);
-            prof_end(L.stream);
-            in1 = L.actbuf[l];
-        }
-        launch_conv(L, rb.conv1, in1, nullptr, split ? nullptr : L.ab, nullptr, tmp, nullptr, nullptr, nimg, Ht, Wt, Ht, Wt,
-                    capture_ ? (name + ".h").c_str() : nullptr);
-        launch_gn(L, rb.gn2, nimg, Ht, Wt, tiles(Ht, Wt, rb_tile_h_), d_film);
-        const unsigned short* in2 = tmp;
-        if (split) {   // h is only ever read through GN2+SiLU: activate into the spare buffer (capture keeps raw h)
-            prof_begin(FAM_GN, L.stream, 0, 2.0 * nimg * Ht * Wt * C * 2);
-            gn_apply_silu_launch(tmp, L.ab, L.actbuf[l], nimg, Ht * Wt, C, L.stream);
-            prof_end(L.stream);
-            in2 = L.actbuf[l];
-        }
-        launch_conv(L, rb.conv2, in2, nullptr, split ? nullptr : L.ab, x, out, nullptr, nullptr, nimg, Ht, Wt, Ht, Wt,
-                    capture_ ? name.c_str() : nullptr);
-    };
-
-    // stem
-    launch_conv(L, net_.stem, d_in, nullptr, nullptr, nullptr, L.act[0][0], nullptr, nullptr, nimg, h, w, h, w, "stem");
-    int cur_tiles = tiles(h, w, 8);
-    const unsigned short* x = L.act[0][0];
-    // encoder
-    for (int l = 0; l < 4; ++l) {
-        const int Ht = h >> l, Wt = w >> l;
-        unsigned short* rb1_out = (l < 3) ? L.skip[l] : L.act[l][3];
-        resblock(net_.enc[l][0], x, L.act[l][1], L.act[l][2], l, cur_tiles, "enc" + std::to_string(l) + ".rb0");
-        resblock(net_.enc[l][1], L.act[l][2], L.act[l][1], rb1_out, l, tiles(Ht, Wt, rb_tile_h_), "enc" + std::to_string(l) + ".rb1");
-        if (l < 3) {
-            launch_conv(L, net_.down[l], rb1_out, nullptr, nullptr, nullptr, L.act[l + 1][0], nullptr, nullptr, nimg, Ht,
-                        Wt, Ht / 2, Wt / 2, capture_ ? ("down" + std::to_string(l)).c_str() : nullptr);
-            x = L.act[l + 1][0];
-            cur_tiles = tiles(Ht / 2, Wt / 2, 4);
-        }
-    }
-    // bottleneck at level 3
-    {
-        const int Ht = h >> 3, Wt = w >> 3;
-        resblock(net_.mid[0], L.act[3][3], L.act[3][1], L.act[3][0], 3, tiles(Ht, Wt, rb_tile_h_), "mid.rb0");
-        resblock(net_.mid[1], L.act[3][0], L.act[3][1], L.act[3][2], 3, tiles(Ht, Wt, rb_tile_h_), "mid.rb1");
-    }
-    const unsigned short* deep = L.act[3][2];
-    // decoder
-    for (int l = 2; l >= 0; --l) {
-        const int Ht = h >> l, Wt = w >> l;
-        const std::string s = std::to_string(l);
-        launch_conv(L, net_.up[l], deep, nullptr, nullptr, nullptr, L.act[l][0], nullptr, nullptr, nimg, Ht / 2, Wt / 2, Ht,
-                    Wt, capture_ ? ("up" + s).c_str() : nullptr);
-        launch_conv(L, net_.fuse[l], L.act[l][0], L.skip[l], nullptr, nullptr, L.act[l][2], nullptr, nullptr, nimg, Ht, Wt,
-                    Ht, Wt, capture_ ? ("fuse" + s).c_str() : nullptr);
-        resblock(net_.dec[l][0], L.act[l][2], L.act[l][1], L.act[l][3], l, tiles(Ht, Wt, 8), "dec" + s + ".rb0");
-        resblock(net_.dec[l][1], L.act[l][3], L.act[l][1], L.act[l][0], l, tiles(Ht, Wt, rb_tile_h_), "dec" + s + ".rb1");
-        deep = L.act[l][0];
-    }
-    // head
-    launch_gn(L, net_.head_gn, nimg, h, w, tiles(h, w, rb_tile_h_), d_film);
-    launch_conv(L, net_.head, deep, nullptr, L.ab, nullptr, nullptr, d_in, d_out, nimg, h, w, h, w, nullptr);
+    Run R;
+    R.stream = L.stream; R.stats = L.stats; R.ab = L.ab; R.film = d_film;
+    const Geo g = geo_of_lane(L, nimg, h, w, d_in, d_out);
+    for (const Op& op : program_) exec_op(R, op, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -707,6 +745,26 @@ void Engine::restore_device(const uint8_t* d_rgb, int n, int h, int w, const dou
         IRE_HIP(hipEventRecord(L.done, L.stream));
         IRE_HIP(hipStreamWaitEvent(stream, L.done, 0));
     }
+}
+
+void Engine::restore_tiled_device(const uint8_t* d_rgb, int h, int w, int nstrips, const double* d_scores, const uint8_t* d_is_jpeg,
+                                  uint8_t* d_out, hipStream_t stream) {
+    if (!d_rgb || !d_out) fail(IRE_ERR_INVALID_INPUT, "invalid input: null image pointer");
+    if (!tiled_ || tiled_h_ != h || tiled_w_ != w || tiled_n_ != nstrips) {
+        IRE_HIP(hipDeviceSynchronize());
+        delete tiled_; tiled_ = nullptr;
+        tiled_ = new StripSession(*this, h, w, nstrips, 0, nstrips, nullptr);
+        tiled_h_ = h; tiled_w_ = w; tiled_n_ = nstrips;
+    }
+    ensure_io(1, 1, 1);
+    if (!d_scores) {
+        prof_begin(FAM_CLASSIFIER, stream, 0, (double)h * w * 3);
+        classifier_launch(tables_, d_rgb, 1, h, w, d_is_jpeg, d_sums_, d_scores_, d_label_, d_cond_, stream);
+        prof_end(stream);
+        d_scores = d_scores_;
+    }
+    batches_run_ += 1; images_restored_ += 1; last_batch_ = 1;
+    tiled_->run_all(d_rgb, d_scores, d_out, stream);
 }
 
 void Engine::restore_device_mixed(const uint8_t* d_rgb, int n, int h, int w, const double* host_scores, const uint8_t* has_scores,

@@ -58,8 +58,42 @@ struct Lane {
     unsigned short* skip[3] = {};
     unsigned short* actbuf[4] = {};   // activated copy of a ResBlock conv input (levels with C >= act_split_min_c)
     float* stats = nullptr;
-    int stat_parts = 0;              // partials per image the last stats-producing conv wrote (tiles, or workgroup slots)
     float2* ab = nullptr;
+};
+
+// ---- the layer schedule as a program (engine.cpp::build_program): one list of ops, executed op by op either over a whole
+// batch (restore_device) or over the row strips of one image with a halo exchange after every op whose output feeds a
+// 3x3 convolution and a gather of the GroupNorm partials before every OP_GN (cfg 4: engine.cpp "strips") ----
+constexpr int BUF_NONE = -1;
+inline int buf_id(int level, int slot) { return level * 8 + slot; }   // slot 0..3 = act[level][slot], 4 = skip[level], 5 = actbuf[level]
+struct Op {
+    enum Kind { GN, ACT, CONV } kind = CONV;
+    const GNW* gn = nullptr;          // GN: finalize the partials of the tensor produced last -> (A, B) per (image, channel)
+    const ConvW* cw = nullptr;        // CONV
+    int in0 = BUF_NONE, in1 = BUF_NONE, resid = BUF_NONE, out = BUF_NONE;   // ACT: in0 -> out
+    int lin = 0, lout = 0;            // levels of in0 / out
+    bool use_ab = false;              // CONV: GroupNorm+FiLM+SiLU applied while staging in0
+    bool halo_out = false;            // the output is read by a 3x3 convolution: strips exchange its boundary rows
+    bool stats_out = false;           // the conv writes GroupNorm partials of its output
+    std::string name;                 // debug-capture name ("" = none)
+};
+// state shared by everything one network run touches on one stream (a lane, or all strips of a tiled image)
+struct Run {
+    hipStream_t stream = nullptr;
+    float* stats = nullptr;           // [image][tile][8 groups][2] partials of the tensor produced last
+    float2* ab = nullptr;             // [image][C] coefficients of the GroupNorm finalized last
+    const float* film = nullptr;
+    int stat_parts = 0;               // partials per image the last stats-producing conv wrote
+};
+// where one executor instance's rows live: a whole batch (halo = 0) or one row strip of one image (halo = 1)
+struct Geo {
+    int nimg = 1, h = 0, w = 0;       // rows / columns of THIS piece at level 0
+    int halo = 0;                     // halo rows above and below in every activation buffer and in img_in
+    bool has_up = false, has_down = false;
+    int y0 = 0, H = 0;                // first global row of the piece and global image height (level 0)
+    unsigned short* buf[4][6] = {};   // buffer starts (halo row included)
+    const uint8_t* img_in = nullptr;  // u8 image rows of the piece, halo rows included
+    uint8_t* img_out = nullptr;       // u8 output rows of the piece (no halo)
 };
 
 struct ProfRec {
@@ -69,6 +103,7 @@ struct ProfRec {
 };
 
 class Engine {
+    friend class StripSession;
 public:
     explicit Engine(const ire_config& cfg);
     ~Engine();
@@ -117,6 +152,9 @@ public:
     // device bytes one more image of this shape costs (activation workspace + staging), and how many fit right now
     size_t bytes_per_image(int h, int w) const;
     int capacity_for(int h, int w) const;
+    // cfg 4: the whole image on this GPU as nstrips "virtual ranks" (strips.cpp); d_scores null => classify inside
+    void restore_tiled_device(const uint8_t* d_rgb, int h, int w, int nstrips, const double* d_scores, const uint8_t* d_is_jpeg,
+                              uint8_t* d_out, hipStream_t stream);
     void get_stats(ire_engine_stats* out);                            // counters + the images/sec gauge (queue_depth is the ABI layer's)
     // batcher form of restore_device: rows of host_scores (pinned, n*7) flagged in has_scores are used as given, the rest are
     // classified inside (one scan over the batch, skipped when every job brought its scores)
@@ -131,11 +169,11 @@ private:
     void ensure_io(int n, int h, int w);
     void ensure_workspace(int n, int h, int w);
     void free_workspace();
+    void build_program();
     void run_network(Lane& L, int nimg, int h, int w, const uint8_t* d_in, uint8_t* d_out, const float* d_film);
-    void launch_conv(Lane& L, const ConvW& cw, const void* in0, const void* in1, const float2* ab,
-                     const unsigned short* resid, unsigned short* out, const uint8_t* u8_in, uint8_t* u8_out,
-                     int nimg, int Hin, int Win, int Hout, int Wout, const char* cap_name);
-    void launch_gn(Lane& L, const GNW& g, int nimg, int Ht, int Wt, int ntiles, const float* d_film);
+    void exec_op(Run& R, const Op& op, const Geo& g);
+    void exec_conv(Run& R, const Op& op, const Geo& g);
+    static Geo geo_of_lane(const Lane& L, int nimg, int h, int w, const uint8_t* d_in, uint8_t* d_out);
     void prof_begin(int fam, hipStream_t s, double flops, double bytes);
     void prof_end(hipStream_t s);
     void capture(const char* name, const unsigned short* d, size_t count, hipStream_t s);
@@ -197,6 +235,9 @@ private:
 
     // network
     Net net_;
+    std::vector<Op> program_;
+    class StripSession* tiled_ = nullptr;      // cached session of restore_tiled_device (one shape at a time)
+    int tiled_h_ = 0, tiled_w_ = 0, tiled_n_ = 0;       // the layer schedule (build_program; rebuilt by load_weights)
     std::map<std::string, std::pair<std::vector<int>, std::vector<float>>> host_w_;
     std::vector<Lane> lanes_;
     int ws_imgs_per_lane_ = 0, ws_imgs_cap_ = 0, ws_h_ = 0, ws_w_ = 0;

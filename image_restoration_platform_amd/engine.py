@@ -215,6 +215,24 @@ class Engine:
                                               self._stream_ptr(stream)))
         return out, shifts
 
+    # ---- cfg 4: row strips ----------------------------------------------------------------------
+    def restore_tiled_tensor(self, rgb_u8, nstrips, out_u8=None, scores=None, is_jpeg_u8=None, stream=None):
+        """One [H,W,3] image restored as `nstrips` row strips on this GPU (virtual ranks: per-level halo exchange and the
+        GroupNorm partials gather are in-device copies).  Bit-identical to restore_tensor on the whole image."""
+        import torch
+        assert rgb_u8.is_cuda and rgb_u8.dtype == torch.uint8 and rgb_u8.is_contiguous() and rgb_u8.dim() == 3
+        h, w, _ = rgb_u8.shape
+        if out_u8 is None:
+            out_u8 = torch.empty_like(rgb_u8)
+        sc = ctypes.c_void_p(scores.data_ptr()) if scores is not None else None
+        jp = ctypes.c_void_p(is_jpeg_u8.data_ptr()) if is_jpeg_u8 is not None else None
+        self._check(self._lib.ire_restore_tiled_device(self._h, ctypes.c_void_p(rgb_u8.data_ptr()), h, w, int(nstrips), sc, jp,
+                                                       ctypes.c_void_p(out_u8.data_ptr()), self._stream_ptr(stream)))
+        return out_u8
+
+    def open_strips(self, h, w, nstrips_total, first_strip, nlocal=1):
+        return StripSession(self, h, w, nstrips_total, first_strip, nlocal)
+
     # ---- diagnostics --------------------------------------------------------------------------
     def classifier_sums(self, n):
         sums = np.zeros((n, 14), np.uint64)
@@ -243,3 +261,60 @@ class Engine:
         self._check(self._lib.ire_profile_query(self._h, family.encode(), ctypes.byref(ms), ctypes.byref(n),
                                                 ctypes.byref(fl), ctypes.byref(by)))
         return {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+
+
+class StripSession:
+    """One rank's strips of a tiled restoration (include/ire.h "cfg 4"): the layer program runs one op at a time and the host
+    moves halo rows / GroupNorm partials between ranks in between (tiled.py).  All buffers the ranks exchange are torch tensors
+    owned here: `stats` (the global partials array, all-gathered in place) and four halo staging rows."""
+
+    def __init__(self, engine, h, w, nstrips_total, first_strip, nlocal=1):
+        import torch
+        self.eng, self._lib = engine, engine._lib
+        self.h, self.w, self.total, self.first, self.nlocal = h, w, nstrips_total, first_strip, nlocal
+        self.rows = (h // nstrips_total) * nlocal
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.stats = torch.zeros(int(self._lib.ire_strips_stats_bytes(h, w)), dtype=torch.uint8, device=dev)
+        row_max = w * 32 * 2                       # W_l * C_l * 2 bytes is the same at every level
+        self.send_up, self.send_down, self.recv_up, self.recv_down = (torch.zeros(row_max, dtype=torch.uint8, device=dev) for _ in range(4))
+        hnd = ctypes.c_void_p()
+        self._s = None
+        engine._check(self._lib.ire_strips_open(engine._h, h, w, nstrips_total, first_strip, nlocal, ctypes.c_void_p(self.stats.data_ptr()),
+                                                ctypes.byref(hnd)))
+        self._s = hnd
+        self.num_ops = int(self._lib.ire_strips_num_ops(self._s))
+
+    def close(self):
+        if getattr(self, "_s", None):
+            self._lib.ire_strips_close(self._s)
+            self._s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_input(self, rows_with_halo_u8, scores_f64, stream=None):
+        assert rows_with_halo_u8.is_cuda and rows_with_halo_u8.is_contiguous() and tuple(rows_with_halo_u8.shape) == (self.rows + 2, self.w, 3)
+        self.eng._check(self._lib.ire_strips_set_input(self._s, ctypes.c_void_p(rows_with_halo_u8.data_ptr()), ctypes.c_void_p(scores_f64.data_ptr()),
+                                                       Engine._stream_ptr(stream)))
+
+    def run_op(self, k, stream=None):
+        info = _lib.IreStripXchg()
+        self.eng._check(self._lib.ire_strips_run_op(self._s, int(k), Engine._stream_ptr(stream), ctypes.byref(info)))
+        return info
+
+    def pack_halo(self, k, stream=None):
+        self.eng._check(self._lib.ire_strips_pack_halo(self._s, int(k), ctypes.c_void_p(self.send_up.data_ptr()), ctypes.c_void_p(self.send_down.data_ptr()),
+                                                       Engine._stream_ptr(stream)))
+
+    def unpack_halo(self, k, stream=None):
+        self.eng._check(self._lib.ire_strips_unpack_halo(self._s, int(k), ctypes.c_void_p(self.recv_up.data_ptr()), ctypes.c_void_p(self.recv_down.data_ptr()),
+                                                         Engine._stream_ptr(stream)))
+
+    def get_output(self, stream=None):
+        import torch
+        out = torch.empty((self.rows, self.w, 3), dtype=torch.uint8, device=self.stats.device)
+        self.eng._check(self._lib.ire_strips_get_output(self._s, ctypes.c_void_p(out.data_ptr()), Engine._stream_ptr(stream)))
+        return out

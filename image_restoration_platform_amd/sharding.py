@@ -85,3 +85,53 @@ def restore_views_and_fuse(view, group_ranks, dst, restore, fuse):
     if views is None:
         return None
     return fuse(views)
+
+
+# ---- cfg 4: row strips of one large image, one strip per rank -------------------------------------------
+def _staged(t):
+    """gloo moves host memory: stage device tensors through the host under gloo (tests / single-GPU rehearsal); RCCL takes them as is."""
+    return t.is_cuda and dist.get_backend() != "nccl"
+
+
+def exchange_halos(send_up, send_down, recv_up, recv_down, nbytes, rank=None, world=None):
+    """Per-level halo exchange between neighbouring strips: my first row goes to the rank above (its lower halo), my last row to
+    the rank below (its upper halo); theirs arrive in recv_up / recv_down.  Point-to-point on the direct xGMI links of the two
+    neighbours (batch_isend_irecv = one grouped RCCL launch), never a collective.  Tensors are flat uint8; nbytes <= their size."""
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    if world == 1 or nbytes == 0:
+        return
+    stage = _staged(send_up)
+    su, sd = (send_up[:nbytes].cpu(), send_down[:nbytes].cpu()) if stage else (send_up[:nbytes], send_down[:nbytes])
+    ru = torch.empty(nbytes, dtype=torch.uint8) if stage else recv_up[:nbytes]
+    rd = torch.empty(nbytes, dtype=torch.uint8) if stage else recv_down[:nbytes]
+    ops = []
+    if rank > 0:
+        ops += [dist.P2POp(dist.isend, su, rank - 1), dist.P2POp(dist.irecv, ru, rank - 1)]
+    if rank + 1 < world:
+        ops += [dist.P2POp(dist.isend, sd, rank + 1), dist.P2POp(dist.irecv, rd, rank + 1)]
+    for q in dist.batch_isend_irecv(ops):
+        q.wait()
+    if stage:
+        if rank > 0:
+            recv_up[:nbytes].copy_(ru)
+        if rank + 1 < world:
+            recv_down[:nbytes].copy_(rd)
+
+
+def allgather_parts(buf, offset, local, total):
+    """GroupNorm partial statistics: every rank wrote `local` bytes at `offset` of the flat uint8 tensor `buf` (equal slices,
+    rank order); afterwards every rank holds all `total` bytes.  An all-GATHER of the per-tile partials, not an all-reduce:
+    the finalize then sums exactly the partials of the untiled run in exactly its order, so the result is bit-identical
+    (and the payload is small: 64 B per tile).  In place under RCCL."""
+    world = dist.get_world_size()
+    if world == 1 or local == 0:
+        return
+    assert local * world == total and offset == dist.get_rank() * local
+    if _staged(buf):
+        mine = buf[offset:offset + local].cpu()
+        full = torch.empty(total, dtype=torch.uint8)
+        dist.all_gather_into_tensor(full, mine)
+        buf[:total].copy_(full)
+    else:
+        dist.all_gather_into_tensor(buf[:total], buf[offset:offset + local])

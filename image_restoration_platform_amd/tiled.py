@@ -1,0 +1,79 @@
+"""cfg 4 of BASELINE.json: one large image (the reference caps uploads at 2048 px: imagePreprocess.js:4) restored as row
+strips -- one strip per GPU of the node, or all strips on one GPU as "virtual ranks" (Engine.restore_tiled_tensor).
+
+restore_strip() is one rank's side of the multi-GPU flow: the engine runs the layer program one op at a time
+(ire_strips_run_op); after every op whose output a 3x3 convolution reads, the boundary rows travel to the neighbouring
+ranks (sharding.exchange_halos: point-to-point over the direct xGMI links); after every op that wrote GroupNorm partial
+statistics the per-tile partials of all ranks are all-gathered (sharding.allgather_parts).  Nothing else is exchanged;
+the result is bit-identical to the untiled run.
+"""
+import json
+
+import numpy as np
+
+
+def split_rows(img_u8, rank, world):
+    """rows of `img_u8` [H,W,3] (torch, any device) rank owns, with one halo row above and below (zeros outside the image: never read)."""
+    import torch
+    h = img_u8.shape[0]
+    hr = h // world
+    y0 = rank * hr
+    out = torch.zeros((hr + 2,) + tuple(img_u8.shape[1:]), dtype=img_u8.dtype, device=img_u8.device)
+    lo, hi = max(0, y0 - 1), min(h, y0 + hr + 1)
+    out[lo - (y0 - 1):lo - (y0 - 1) + (hi - lo)] = img_u8[lo:hi]
+    return out
+
+
+def restore_strip(sess, rows_with_halo, scores, sharding, stream=None):
+    """This rank's strip through the network.  sess: engine.StripSession (1 strip per rank); returns the strip's restored rows."""
+    sess.set_input(rows_with_halo, scores, stream)
+    for k in range(sess.num_ops):
+        info = sess.run_op(k, stream)
+        if info.halo_bytes:
+            sess.pack_halo(k, stream)
+            sharding.exchange_halos(sess.send_up, sess.send_down, sess.recv_up, sess.recv_down, int(info.halo_bytes))
+            sess.unpack_halo(k, stream)
+        if info.stats_local_bytes:
+            sharding.allgather_parts(sess.stats, int(info.stats_offset_bytes), int(info.stats_local_bytes), int(info.stats_total_bytes))
+    return sess.get_output(stream)
+
+
+def bench(ctx, eng, line, mfma_peak):
+    """bench.py --workload tiled.  N = 1: one size x size image per step as --strips virtual ranks on the GPU.  N > 1: one strip
+    per rank (N must divide the height into strips of a multiple of 128 rows), halo rows and partials over RCCL."""
+    from . import synth, weights
+    a, torch = ctx.args, ctx.torch
+    S = a.size
+    img = torch.from_numpy(synth.batch(1, S, S)[0]).to(ctx.dev)
+    jp = torch.ones(1, dtype=torch.uint8, device=ctx.dev)
+    scores, _ = eng.classify_tensor(img[None], jp)
+    f3, f1 = weights.conv_flops(S, S)
+    if ctx.world == 1:
+        out = torch.empty_like(img)
+
+        def step(i):
+            eng.restore_tiled_tensor(img, a.strips, out_u8=out, scores=scores[0])
+        par = "%d row strips as virtual ranks on one GPU: per-level halo rows and GroupNorm partials by in-device copies" % a.strips
+    else:
+        sess = eng.open_strips(S, S, ctx.world, ctx.rank, 1)
+        rows = split_rows(img, ctx.rank, ctx.world).contiguous()
+
+        def step(i):
+            restore_strip(sess, rows, scores[0], ctx.sharding)
+        par = "%d row strips, one per GPU: per-level halo rows point-to-point, GroupNorm partials all-gathered (RCCL)" % ctx.world
+
+    def start_profile():
+        eng.profile_reset()
+        eng.profile_enable(2)
+
+    dt = ctx.timed(step, before=start_profile)
+    eng.profile_enable(0)
+    c3 = eng.profile_query("conv3x3")
+    if ctx.rank == 0:
+        ach = c3["flops"] / (c3["ms"] * 1e-3) / 1e12 if c3["ms"] > 0 else 0.0
+        print(json.dumps(line(ctx, "restored images/sec @%dx%d tiled (%s)" % (S, S, a.precision), a.steps / dt, dt, a.precision, {
+            "workload": "cfg4: one %dx%d image, RestoreNet-v0 in row strips with per-level halo exchange, %.1f GFLOP/image" % (S, S, (f3 + f1) / 1e9),
+            "parallelism": par}, {
+            "scaling": "strong",
+            "roofline": {"kernel": "conv3x3 family on rank 0 (its strips only)", "bound": "mfma", "achieved": ach, "peak": mfma_peak, "unit": "TFLOP/s",
+                         "frac": ach / mfma_peak, "traffic": None, "launches": c3["launches"]}})))

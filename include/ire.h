@@ -143,6 +143,41 @@ int ire_submit(ire_engine* e, const uint8_t* rgb, int h, int w, int is_jpeg, con
 int ire_poll(ire_engine* e, ire_job* job, int timeout_ms, uint8_t* out_rgb, double* scores_out,
              ire_timings* t);
 
+/* ---- cfg 4: one large image restored as row strips (imagePreprocess.js:4 caps uploads at 2048 px) ----
+ * The image is cut into nstrips equal row strips; every layer runs strip by strip, the boundary rows of every tensor a 3x3
+ * convolution reads are exchanged between neighbouring strips after the layer that produced it (per-level halo exchange),
+ * and the GroupNorm partial statistics of all strips are combined before each GroupNorm.  The result is bit-identical to
+ * ire_restore_device on the whole image.  H must be a multiple of nstrips, rows per strip a multiple of 128, W of 8. */
+/* All strips on this GPU ("virtual ranks": the exchange steps are in-device copies).  d_scores NULL => classify inside. */
+int ire_restore_tiled_device(ire_engine* e, const uint8_t* d_rgb, int h, int w, int nstrips, const double* d_scores,
+                             const uint8_t* d_is_jpeg, uint8_t* d_out_rgb, void* stream);
+/* One rank of the multi-GPU layout: a session owns strips [first_strip, first_strip + nlocal) and runs the layer program one
+ * op at a time; between ops the HOST moves halo rows and statistics between ranks (sharding.py: send/recv + all_gather over
+ * RCCL).  d_stats_all: device buffer of ire_strips_stats_bytes(h, w) bytes owned by the caller (a torch tensor): the global
+ * array of GroupNorm partials, of which this session fills its slice. */
+typedef struct ire_strips ire_strips;
+typedef struct ire_strip_xchg {   /* what op k left to exchange */
+    int32_t halo_bytes;           /* bytes of one boundary row of the op's output (0: nothing to exchange) */
+    int32_t has_up, has_down;     /* this session has a remote neighbour above / below */
+    int64_t stats_offset_bytes;   /* slice of d_stats_all this session just wrote ... */
+    int64_t stats_local_bytes;    /* ... its size (0: the op wrote no statistics) ... */
+    int64_t stats_total_bytes;    /* ... and the size of the complete array for this op (equal slices per strip) */
+} ire_strip_xchg;
+size_t ire_strips_stats_bytes(int h, int w);
+int ire_strips_open(ire_engine* e, int h, int w, int nstrips_total, int first_strip, int nlocal, void* d_stats_all, ire_strips** out);
+void ire_strips_close(ire_strips* s);
+int ire_strips_num_ops(ire_strips* s);
+/* d_rows_with_halo: (nlocal*rows_per_strip + 2) x w x 3: the session's rows with one row above and below (rows outside the
+ * image are never read); d_scores: the 7 classifier scores of the WHOLE image (the rank that took the job classified it). */
+int ire_strips_set_input(ire_strips* s, const uint8_t* d_rows_with_halo, const double* d_scores, void* stream);
+int ire_strips_run_op(ire_strips* s, int k, void* stream, ire_strip_xchg* info);
+/* copy the first / last real row of op k's output into d_send_up / d_send_down (halo_bytes each; NULL or no neighbour: skipped) */
+int ire_strips_pack_halo(ire_strips* s, int k, uint8_t* d_send_up, uint8_t* d_send_down, void* stream);
+/* copy the neighbours' rows into the halo rows of op k's output */
+int ire_strips_unpack_halo(ire_strips* s, int k, const uint8_t* d_recv_up, const uint8_t* d_recv_down, void* stream);
+/* d_out_rows: nlocal*rows_per_strip x w x 3 */
+int ire_strips_get_output(ire_strips* s, uint8_t* d_out_rows, void* stream);
+
 /* ---- service gauges (getHealthStatus + /health/ready dependency entry: restorator.js:289-314, healthRouter.js:80-117) ---- */
 typedef struct ire_engine_stats {
     uint32_t struct_size;   /* = sizeof(ire_engine_stats) */

@@ -118,3 +118,60 @@ def test_cfg3_restore_on_three_ranks_gather_fuse_equals_single_process():
         p.join(60)
         assert p.exitcode == 0
     assert res[0] == (0, True, (64, 64, 3)) and res[1][1] is None and res[2][1] is None
+
+
+def _strip_worker(rank, world, port, q):
+    """cfg 4 on CPU tensors: a toy 3-layer strip network (3x3 box sums with zero padding at the image border, then a global
+    normalisation by statistics every strip contributes to) decomposed into row strips that talk ONLY through the product's
+    exchange functions; the assembled result must equal the whole-image computation exactly (integer arithmetic)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        H, W, hr = 8 * world, 6, 8
+        rng = np.random.default_rng(3)
+        img = rng.integers(0, 50, (H, W)).astype(np.int64)
+
+        def layer(x_with_halo):            # rows 0 and -1 are halo rows (zeros where the image ends)
+            p = np.pad(x_with_halo, ((0, 0), (1, 1)))
+            return sum(p[dy:dy + x_with_halo.shape[0] - 2, dx:dx + W] for dy in range(3) for dx in range(3))
+
+        def whole(x):
+            for _ in range(3):
+                x = layer(np.pad(x, ((1, 1), (0, 0))))
+                x = x - int(x.sum()) // x.size                     # "GroupNorm": a global statistic
+            return x
+
+        x = img[rank * hr:(rank + 1) * hr].copy()
+        row_bytes = W * 8
+        su, sd, ru, rd = (torch.zeros(row_bytes, dtype=torch.uint8) for _ in range(4))
+        parts = torch.zeros(world * 8, dtype=torch.uint8)            # one int64 partial per strip
+        for _ in range(3):
+            su.copy_(torch.from_numpy(x[0].copy().view(np.uint8)))
+            sd.copy_(torch.from_numpy(x[-1].copy().view(np.uint8)))
+            ru.zero_(); rd.zero_()
+            sharding.exchange_halos(su, sd, ru, rd, row_bytes)
+            up = ru.numpy().view(np.int64) if rank > 0 else np.zeros(W, np.int64)
+            dn = rd.numpy().view(np.int64) if rank + 1 < world else np.zeros(W, np.int64)
+            x = layer(np.concatenate([up[None], x, dn[None]], axis=0))
+            parts[rank * 8:(rank + 1) * 8] = torch.from_numpy(np.array([x.sum()], np.int64).view(np.uint8))
+            sharding.allgather_parts(parts, rank * 8, 8, world * 8)
+            x = x - int(parts.numpy().view(np.int64).sum()) // (H * W)
+        q.put((rank, x, whole(img)[rank * hr:(rank + 1) * hr]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cfg4_strip_exchange_functions_reproduce_the_whole_image():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_strip_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(3)]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, got, want in res:
+        assert (got == want).all(), rank

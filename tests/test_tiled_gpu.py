@@ -1,0 +1,100 @@
+"""cfg 4 (BASELINE.json configs[4]): one large image restored as row strips with per-level halo exchange
+and a gather of the GroupNorm partial statistics.  The bar: BIT-IDENTICAL to the untiled run (same tiles, same per-tile fp32
+partial sums, same double-precision finalize order) -- first as virtual ranks on one GPU (in-device copies), then as two
+processes that exchange halo rows and partials through torch.distributed (sharding.exchange_halos / allgather_parts;
+gloo with host staging here because the box has one GPU -- the same functions run over RCCL on a node)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from image_restoration_platform_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("h,w,n", [(512, 512, 2), (512, 384, 4), (1024, 256, 8), (256, 264, 1)])
+def test_tiled_equals_untiled_bitwise(engine, h, w, n):
+    import torch
+    img = torch.from_numpy(synth.batch(1, h, w, start=h // 64 + n)[0]).cuda()
+    jp = torch.ones(1, dtype=torch.uint8, device="cuda")
+    whole = engine.restore_tensor(img[None], is_jpeg_u8=jp)[0].clone()
+    tiled = engine.restore_tiled_tensor(img, n, is_jpeg_u8=jp).clone()
+    again = engine.restore_tiled_tensor(img, n, is_jpeg_u8=jp)
+    torch.cuda.synchronize()
+    assert torch.equal(tiled, whole), int((tiled.int() - whole.int()).abs().max())
+    assert torch.equal(again, whole)
+    assert (whole.int() - img.int()).abs().float().mean().item() > 1.0
+
+
+def test_2048_in_8_strips_equals_untiled(engine):
+    """The BASELINE shape: 2048x2048, 8 strips of 256 rows (one per GPU of the node; here 8 virtual ranks)."""
+    import torch
+    img = torch.from_numpy(synth.batch(1, 2048, 2048)[0]).cuda()
+    whole = engine.restore_tensor(img[None])[0].clone()
+    tiled = engine.restore_tiled_tensor(img, 8)
+    torch.cuda.synchronize()
+    assert torch.equal(tiled, whole)
+
+
+def test_invalid_strip_plans_are_rejected(engine):
+    import torch
+    from image_restoration_platform_amd.engine import EngineError
+    img = torch.zeros((512, 512, 3), dtype=torch.uint8, device="cuda")
+    for n in (3, 8, 0):                       # 512/3 not integral; 512/8 = 64 rows (not a multiple of 128); 0 strips
+        with pytest.raises(EngineError) as e:
+            engine.restore_tiled_tensor(img, n)
+        assert e.value.status == 1 and "invalid" in e.value.message
+
+
+def _rank(rank, world, port, h, w, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from image_restoration_platform_amd import sharding, tiled
+    from image_restoration_platform_amd.engine import Engine
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        eng = Engine(device_index=0, max_batch=1)
+        img = torch.from_numpy(synth.batch(1, h, w, start=77)[0]).cuda()
+        jp = torch.ones(1, dtype=torch.uint8, device="cuda")
+        scores, _ = eng.classify_tensor(img[None], jp)           # "the rank that took the job classified it"; here every rank can
+        sess = eng.open_strips(h, w, world, rank, 1)
+        rows = tiled.split_rows(img, rank, world).contiguous()
+        out = tiled.restore_strip(sess, rows, scores[0], sharding)
+        torch.cuda.synchronize()
+        ok = None
+        if rank == 0:
+            whole = eng.restore_tensor(img[None], scores=scores)[0]
+            torch.cuda.synchronize()
+            ok = whole.cpu().numpy()
+        q.put((rank, out.cpu().numpy(), ok))
+        sess.close()
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_exchange_halos_and_partials_bit_identical():
+    """Two processes, one strip each: the product's own exchange functions between them (torch.distributed), result == untiled."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    h, w = 256, 192
+    ps = [ctx.Process(target=_rank, args=(r, 2, port, h, w, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda t: t[0])
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    whole = res[0][2]
+    got = np.concatenate([res[0][1], res[1][1]], axis=0)
+    assert got.shape == whole.shape == (h, w, 3)
+    assert np.array_equal(got, whole), int(np.abs(got.astype(int) - whole.astype(int)).max())
