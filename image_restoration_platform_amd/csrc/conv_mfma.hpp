@@ -43,6 +43,8 @@ struct ConvArgs {
     int in_rows;                 // allocated rows per image of in0 / in1
     int in_row_off;              // buffer row of local row 0
     int iy_lo, iy_span;
+    int fp8;                     // conv_w4: OCP e4m3 operands (a.w = fp8 slabs, a.bias = bias / oscale)
+    const float* oscale;         // fp8: [cout] accumulator -> output scale (weight scale of the channel / activation scale)
     int w4_waves;                // conv_w4 on a pre-activated input (ab == nullptr): 8 (default) or 4 waves per workgroup
     unsigned long long* stamps;  // diagnostic builds only (IRE_RB_ABLATE, DBG bit 16): s_memtime stamps, else null
 };

@@ -17,6 +17,7 @@
 #include "conv_mfma.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace ire {
 
@@ -66,27 +67,42 @@ template <int N> struct W4Regs { u32x4_t v[N]; unsigned ok; };   // native 128-b
 // WAVES = 4: one wave per SIMD, wave tile 4 rows x NT couts (all 256 AGPRs are accumulators at NT = 128)
 // WAVES = 8: two waves per SIMD, wave tile 2 rows x NT couts (128 accumulators): a partner wave's MFMAs cover this wave's
 //            VMEM / LDS-DMA / epilogue issue slots, which a single wave per SIMD can only serialise
-template <int NT, int WAVES>
+// FP8 (IRE_PRECISION_FP8, cfg 4): both MFMA operands are OCP e4m3 (v_mfma_f32_32x32x16_fp8_fp8): an 8-channel operand chunk
+// is 8 bytes instead of 16 in the LDS tile and in the weight slab (ds_read_b64 fragments, half the LDS bytes per MFMA).
+// Activations are quantised while staging -- after GroupNorm+FiLM+SiLU, scaled by kFp8ActScale so that small values stay
+// normal numbers, clamped to the e4m3 range -- weights offline with one scale per output channel (engine.cpp::make_conv);
+// the epilogue multiplies each accumulator by its channel's (weight scale / kFp8ActScale).  HBM tensors stay bf16.
+constexpr float kFp8ActScale = 16.0f;
+template <int NT, int WAVES, bool FP8 = false>
 struct W4Cfg {
     static constexpr int THREADS = WAVES * 64;
     static constexpr int MT = W4_TH / WAVES;
     static constexpr int IN_ITERS = (W4_IN_CHUNKS + THREADS - 1) / THREADS;
     static constexpr int NTL = NT / 32;
-    static constexpr int W_CHUNKS = W4_NSTEPS * 2 * NT;        // [tap][c8][NT] x 16 B
-    static constexpr int W_BYTES = W_CHUNKS * 16;
+    static constexpr int EB = FP8 ? 8 : 16;                     // bytes of one 8-channel operand chunk in LDS
+    // one k-half plane of the input tile: 612 pixels x EB, sized so that (PLANE / 4) % 32 == 16 (conflict-free tile writes)
+    static constexpr int PLANE = FP8 ? 4928 : (W4_IN_CHUNKS / 2) * 16;
+    static constexpr int IN_BYTES = FP8 ? 2 * 4928 + 64 : W4_IN_BYTES;      // + dummy slot (chunk slots past the tile)
+    static constexpr int W_BYTES = W4_NSTEPS * 2 * NT * EB;    // slab [tap][c8][NT] x EB
+    static constexpr int W_CHUNKS = W_BYTES / 16;              // 16-B pieces of a slab (LDS-DMA granule)
     static constexpr int W_ITERS = (W_CHUNKS + THREADS - 1) / THREADS;
-    static constexpr int W_BASE = 2 * W4_IN_BYTES;             // in[2] | w[3]
+    static constexpr int W_BASE = 2 * IN_BYTES;                // in[2] | w[3]
     static constexpr int MAIN_BYTES = W_BASE + 3 * W_BYTES;
     static constexpr int RED_BYTES = WAVES * 8 * 2 * 4;        // [waves][8 slots of 16 couts][sum, sumsq]
     static constexpr int BIAS_BYTES = 256 * 4;
     static constexpr int COEF_BYTES = WAVES * 128;             // FUSED: per wave, 16 channels x (A, B) of the stage being staged
-    static constexpr int LDS_BYTES = MAIN_BYTES + RED_BYTES + BIAS_BYTES + COEF_BYTES;
+    static constexpr int SCALE_BYTES = FP8 ? 256 * 4 : 0;      // FP8: per-cout output scale
+    static constexpr int LDS_BYTES = MAIN_BYTES + RED_BYTES + BIAS_BYTES + COEF_BYTES + SCALE_BYTES;
+    static_assert((PLANE / 4) % 32 == 16, "plane offset must be half a bank row");
+    static_assert(W_CHUNKS % 64 == 0, "slab = whole wave-instructions of LDS-DMA");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int NT, int WAVES, bool RESID, bool UPS, int DBG = 0, bool FUSED = false>
+template <int NT, int WAVES, bool RESID, bool UPS, int DBG = 0, bool FUSED = false, bool FP8 = false>
 __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
-    using C = W4Cfg<NT, WAVES>;
+    static_assert(!FP8 || (FUSED && WAVES == 8), "fp8 operands: fused-activation 8-wave form only");
+    using C = W4Cfg<NT, WAVES, FP8>;
+    constexpr int EB = C::EB;
     using Regs = W4Regs<C::IN_ITERS>;
     constexpr int NTL = C::NTL;
     __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
@@ -133,10 +149,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
     // p = (4*wave + m + ky)*34 + r + kx of plane h: ONE address register + immediates, and the 16 lanes a ds_read_b128
     // services together ({0-3,12-15,20-27}...) hit 16 distinct 16-B slots.  PLANE/4 mod 32 == 16, so the 8-lane groups
     // of the ds_write_b128 (4 pixels x 2 planes) are conflict-free too.
-    constexpr int PLANE = (W4_IN_CHUNKS / 2) * 16;
-    static_assert((PLANE / 4) % 32 == 16, "plane offset must be half a bank row");
-    const int a_base = h * PLANE + (wave * C::MT * W4_IW + r) * 16;
-    const int b_off = (h * NT + r) * 16;
+    constexpr int PLANE = C::PLANE;
+    const int a_base = h * PLANE + (wave * C::MT * W4_IW + r) * EB;
+    const int b_off = (h * NT + r) * EB;
 
     // one 16-B chunk per thread and call: chunk idx = tid + i*256 of the (18 x 34 px) x 2 halves tile of stage si
     auto load_chunk = [&](const StageInfo& si, int i, Regs& R) {
@@ -178,17 +193,24 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
             const float4* ab = reinterpret_cast<const float4*>(coef_lds + c8_fixed * 16);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float4 t = ab[e]; cA[2 * e] = t.x; cB[2 * e] = t.y; cA[2 * e + 1] = t.z; cB[2 * e + 1] = t.w; }
+            if constexpr (FP8) {       // y' = kFp8ActScale * y: silu comes out pre-scaled for the e4m3 conversion at no per-element cost
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { cA[e] *= kFp8ActScale; cB[e] *= kFp8ActScale; }
+            }
         }
     };
-    auto transform_word = [&](unsigned w, int d) -> unsigned {
+    auto transform_pair = [&](unsigned w, int d) -> f32x2_t {        // (kFp8ActScale x) silu(x*A + B) of the word's two channels
         const f32x2_t x = {w4_lo(w), w4_hi(w)};
         const f32x2_t A = {cA[2 * d], cA[2 * d + 1]}, B = {cB[2 * d], cB[2 * d + 1]};
         const f32x2_t y = __builtin_elementwise_fma(x, A, B);
-        const f32x2_t t = y * (-1.4426950408889634f);
+        const f32x2_t t = y * (FP8 ? -1.4426950408889634f / kFp8ActScale : -1.4426950408889634f);
         f32x2_t e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
         e = e + 1.0f;
         const f32x2_t rinv = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
-        const f32x2_t sv = y * rinv;
+        return y * rinv;
+    };
+    auto transform_word = [&](unsigned w, int d) -> unsigned {
+        const f32x2_t sv = transform_pair(w, d);
         return w4_pack(sv.x, sv.y);
     };
     auto store_chunk = [&](int i, const Regs& R, uint4* lds_in) {   // copy (or activate); zero padding outside the image
@@ -198,6 +220,22 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
         const bool ok = (R.ok >> i) & 1u;
         const u32x4_t zero = {0u, 0u, 0u, 0u};
         u32x4_t v = R.v[i];
+        if constexpr (FP8) {
+            // 8 channels -> 8 e4m3 bytes (v_cvt_pk_fp8_f32: round to nearest even); clamped to the format's largest finite value first
+            const unsigned wds[4] = {v.x, v.y, v.z, v.w};
+            int q[2] = {0, 0};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const f32x2_t sv = transform_pair(wds[d], d);
+                const float f0 = __builtin_fminf(sv.x, 448.0f), f1 = __builtin_fminf(sv.y, 448.0f);
+                q[d >> 1] = (d & 1) ? __builtin_amdgcn_cvt_pk_fp8_f32(f0, f1, q[d >> 1], true) : __builtin_amdgcn_cvt_pk_fp8_f32(f0, f1, q[d >> 1], false);
+            }
+            uint2 o8;
+            o8.x = ok ? (unsigned)q[0] : 0u; o8.y = ok ? (unsigned)q[1] : 0u;
+            unsigned char* lb = reinterpret_cast<unsigned char*>(lds_in);
+            *reinterpret_cast<uint2*>(idx < W4_IN_CHUNKS ? lb + c8_fixed * PLANE + (idx >> 1) * 8 : lb + 2 * PLANE) = o8;
+            return;
+        }
         if constexpr (FUSED) { v.x = transform_word(v.x, 0); v.y = transform_word(v.y, 1); v.z = transform_word(v.z, 2); v.w = transform_word(v.w, 3); }
         const u32x4_t o = ok ? v : zero;
         const int slot = c8_fixed * (W4_IN_CHUNKS / 2) + (idx >> 1);
@@ -291,21 +329,29 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
     // allocator park the reloaded R.v[i] in different registers per copy and "fix" that with vmcnt(0) + v_mov after each load
     auto compute = [&](auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;   // the item's last stage: residual prefetch in flight
-        const unsigned char* ib = smem + par * W4_IN_BYTES;
-        uint4* in_nxt = reinterpret_cast<uint4*>(smem + (par ^ 1) * W4_IN_BYTES);
+        const unsigned char* ib = smem + par * C::IN_BYTES;
+        uint4* in_nxt = reinterpret_cast<uint4*>(smem + (par ^ 1) * C::IN_BYTES);
         const unsigned char* wb = smem + C::W_BASE + widx * C::W_BYTES + b_off;
         const int w2 = widx == 0 ? 2 : widx - 1;    // (s + 2) % 3
         const unsigned w_dst_lds = smem_lds + C::W_BASE + w2 * C::W_BYTES;
         stamp(0);
-        bf16x8_t bfr[2][NTL], afr[2][C::MT];
-        auto read_frags = [&](int st, bf16x8_t (&bf)[NTL], bf16x8_t (&af)[C::MT]) {
+        using frag_t = typename std::conditional<FP8, long, bf16x8_t>::type;     // 8 k-values per lane: 8 e4m3 bytes or 8 bf16
+        frag_t bfr[2][NTL], afr[2][C::MT];
+        auto read_frags = [&](int st, frag_t (&bf)[NTL], frag_t (&af)[C::MT]) {
             const int ky = st / 3, kx = st - ky * 3;
+            if constexpr (FP8) {
 #pragma unroll
-            for (int j = 0; j < NTL; ++j)
-                bf[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wb + (2 * st * NT + j * 32) * 16));
+                for (int j = 0; j < NTL; ++j) bf[j] = *reinterpret_cast<const long*>(wb + (2 * st * NT + j * 32) * 8);
 #pragma unroll
-            for (int m = 0; m < C::MT; ++m)
-                af[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ib + a_base + ((m + ky) * W4_IW + kx) * 16));
+                for (int m = 0; m < C::MT; ++m) af[m] = *reinterpret_cast<const long*>(ib + a_base + ((m + ky) * W4_IW + kx) * 8);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NTL; ++j)
+                    bf[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wb + (2 * st * NT + j * 32) * 16));
+#pragma unroll
+                for (int m = 0; m < C::MT; ++m)
+                    af[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ib + a_base + ((m + ky) * W4_IW + kx) * 16));
+            }
         };
         read_frags(0, bfr[0], afr[0]);
 #pragma unroll
@@ -332,7 +378,8 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
             for (int m = 0; m < C::MT; ++m)
 #pragma unroll
                 for (int j = 0; j < NTL; ++j)
-                    if constexpr (!(DBG & 1)) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[(DBG & 2) ? 0 : (st & 1)][j], afr[(DBG & 2) ? 0 : (st & 1)][m], acc[m][j], 0, 0, 0);  // D[cout][pixel]
+                    if constexpr (FP8) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(bfr[st & 1][j], afr[st & 1][m], acc[m][j], 0, 0, 0);
+                    else if constexpr (!(DBG & 1)) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[(DBG & 2) ? 0 : (st & 1)][j], afr[(DBG & 2) ? 0 : (st & 1)][m], acc[m][j], 0, 0, 0);  // D[cout][pixel]
             if (st >= 4) {
                 const int i = st - 4;
                 if (!(DBG & 8) && i < C::IN_ITERS) {
@@ -345,11 +392,11 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
                     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
                     // branch-free issue (a CFG merge here makes hipcc drain vmcnt): waves past the slab's end re-fetch a
                     // chunk group another wave also fetches (same bytes, same destination)
-                    static_assert(C::W_CHUNKS % 256 == 0 && C::W_CHUNKS >= C::THREADS, "slab = whole 256-chunk groups");
+                    static_assert(C::W_CHUNKS >= C::THREADS, "slab >= one workgroup-wide DMA issue");
 #pragma unroll
                     for (int d = 2 * i; d < 2 * i + 2 && d < C::W_ITERS; ++d) {
                         int cbase = d * C::THREADS + wave_u * 64;
-                        if ((d + 1) * C::THREADS > C::W_CHUNKS) cbase = cbase >= C::W_CHUNKS ? cbase - 256 : cbase;
+                        if ((d + 1) * C::THREADS > C::W_CHUNKS) cbase = cbase >= C::W_CHUNKS ? cbase - C::W_CHUNKS : cbase;   // wraps to a 64-aligned group
                         w4_glds16(ws + (size_t)(cbase + lane) * 16, w_dst_lds + cbase * 16);
                     }
                 }
@@ -386,11 +433,20 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
                 b1 = *reinterpret_cast<const float4*>(bias_lds + cout0 + j * 32 + 16 * pp + 8 * h_e + 4);
             }
             float ts = 0.f, tq = 0.f;
+            float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0;
+            if constexpr (FP8) {        // per-cout dequantisation: weight scale / activation scale (the accumulators started at bias / scale)
+                const float* sl = reinterpret_cast<const float*>(smem + C::MAIN_BYTES + C::RED_BYTES + C::BIAS_BYTES + C::COEF_BYTES);
+                s0 = *reinterpret_cast<const float4*>(sl + cout0 + j * 32 + 16 * pp + 8 * h_e);
+                s1 = *reinterpret_cast<const float4*>(sl + cout0 + j * 32 + 16 * pp + 8 * h_e + 4);
+            }
 #pragma unroll
             for (int m = 0; m < C::MT; ++m) {
                 const f32x16_t& c = acc[m][j];
                 unsigned x0, x1, y0, y1;
-                if constexpr (BIAS_INIT) {
+                if constexpr (FP8) {
+                    x0 = w4_pack(c[8 * pp + 0] * s0.x, c[8 * pp + 1] * s0.y); x1 = w4_pack(c[8 * pp + 2] * s0.z, c[8 * pp + 3] * s0.w);
+                    y0 = w4_pack(c[8 * pp + 4] * s1.x, c[8 * pp + 5] * s1.y); y1 = w4_pack(c[8 * pp + 6] * s1.z, c[8 * pp + 7] * s1.w);
+                } else if constexpr (BIAS_INIT) {
                     x0 = w4_pack(c[8 * pp + 0], c[8 * pp + 1]); x1 = w4_pack(c[8 * pp + 2], c[8 * pp + 3]);
                     y0 = w4_pack(c[8 * pp + 4], c[8 * pp + 5]); y1 = w4_pack(c[8 * pp + 6], c[8 * pp + 7]);
                 } else {
@@ -474,6 +530,10 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
     {
         float* bl = reinterpret_cast<float*>(smem + C::MAIN_BYTES + C::RED_BYTES);
         if (tid < a.cout && tid < 256) bl[tid] = a.bias[tid];
+        if constexpr (FP8) {
+            float* sl = reinterpret_cast<float*>(smem + C::MAIN_BYTES + C::RED_BYTES + C::BIAS_BYTES + C::COEF_BYTES);
+            if (tid < a.cout && tid < 256) sl[tid] = a.oscale[tid];
+        }
         load_stage(sq0, R);
         if constexpr (FUSED) stage_coeffs(fetch_coeffs(sq0));
         const uint4* ws0 = reinterpret_cast<const uint4*>(wslab(sq0));
@@ -505,14 +565,14 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the workgroup's LDS is released
 }
 
-template <int NT, int WAVES, bool RESID, bool UPS, int DBG = 0, bool FUSED = false>
+template <int NT, int WAVES, bool RESID, bool UPS, int DBG = 0, bool FUSED = false, bool FP8 = false>
 void launch_w4(const ConvArgs& a, hipStream_t stream) {
     const int items = a.tiles_x * a.tiles_y * a.nimg * a.nblocks;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int grid = items < cus ? items : cus;
-    hipLaunchKernelGGL((conv_w4_kernel<NT, WAVES, RESID, UPS, DBG, FUSED>), dim3(grid), dim3(WAVES * 64), 0, stream, a);
+    hipLaunchKernelGGL((conv_w4_kernel<NT, WAVES, RESID, UPS, DBG, FUSED, FP8>), dim3(grid), dim3(WAVES * 64), 0, stream, a);
     IRE_HIP(hipGetLastError());
 }
 
@@ -536,6 +596,11 @@ void conv_w4_launch(bool resid, const ConvArgs& a, hipStream_t stream) {
 #endif
     // fused activation (a.ab) exists in the 8-wave form only: the 4-wave form is for pre-activated inputs (engine.cpp passes
     // a.w4_waves = 4 only then); asking for it with coefficients would silently skip GroupNorm+SiLU, so refuse
+    if (a.fp8) {
+        if (a.ab == nullptr || a.oscale == nullptr) fail(IRE_ERR_INTERNAL, "internal: fp8 conv_w4 needs the fused activation and the per-channel scales");
+        if (resid) launch_w4<128, 8, true, false, 0, true, true>(a, stream); else launch_w4<128, 8, false, false, 0, true, true>(a, stream);
+        return;
+    }
     if (a.w4_waves == 4 && a.ab != nullptr) fail(IRE_ERR_INTERNAL, "internal: conv_w4 4-wave form has no fused activation");
     if (a.w4_waves == 4) { if (resid) launch_w4<128, 4, true, false>(a, stream); else launch_w4<128, 4, false, false>(a, stream); }
     else if (a.ab != nullptr) { if (resid) launch_w4<128, 8, true, false, 0, true>(a, stream); else launch_w4<128, 8, false, false, 0, true>(a, stream); }

@@ -33,6 +33,27 @@ inline unsigned short f32_to_bf16(float f) {
     return (unsigned short)u;
 }
 
+// fp32 -> OCP e4m3fn (1-4-3, bias 7, no infinities, max 448), round to nearest even, saturating.  Host-side, for weights.
+inline unsigned char f32_to_e4m3(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    const unsigned char sign = (u >> 31) ? 0x80 : 0;
+    float a = std::fabs(f);
+    if (!(a == a)) return sign | 0x7f;
+    if (a >= 448.0f) return sign | 0x7e;
+    if (a < 0.0009765625f) return sign;                         // < 2^-10 = half the smallest subnormal (2^-9): rounds to zero
+    int e;
+    std::frexp(a, &e);                                          // a = m * 2^e, m in [0.5, 1)
+    int E = e - 1;                                              // a = 1.xxx * 2^E
+    if (E < -6) E = -6;                                         // subnormal range: fixed exponent, step 2^-9
+    const float step = std::ldexp(1.0f, E - 3);
+    float q = std::nearbyint(a / step);                         // default rounding mode: to nearest even
+    if (E == -6 && q < 8.0f) return sign | (unsigned char)q;    // subnormal: mantissa only
+    if (q >= 16.0f) { q = 8.0f; E += 1; }
+    if (E > 8) return sign | 0x7e;
+    return sign | (unsigned char)(((E + 7) << 3) | ((int)q - 8));
+}
+
 }  // namespace
 
 void* Engine::dalloc(size_t bytes) {
@@ -54,7 +75,8 @@ Engine::Engine(const ire_config& cfg) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         fail(IRE_ERR_UNAVAILABLE, std::string("service unavailable: device is ") + prop.gcnArchName +
                                       ", this engine is built for gfx950 (MI355X) only");
-    if (cfg.precision != IRE_PRECISION_BF16) fail(IRE_ERR_INVALID_INPUT, "invalid precision: only bf16 is implemented");
+    if (cfg.precision != IRE_PRECISION_BF16 && cfg.precision != IRE_PRECISION_FP8) fail(IRE_ERR_INVALID_INPUT, "invalid precision");
+    precision_ = cfg.precision;
     max_batch_ = cfg.max_batch > 0 ? cfg.max_batch : 8;
     if (max_batch_ > 64) fail(IRE_ERR_INVALID_INPUT, "invalid max_batch (1..64)");
     num_lanes_ = cfg.num_streams > 0 ? cfg.num_streams : 1;
@@ -228,6 +250,38 @@ ConvW Engine::make_conv(ConvKind kind, const std::string& wname, const std::stri
         c.d_w4 = (unsigned short*)dalloc(arr4.size() * 2);
         net_.allocs.push_back(c.d_w4);
         IRE_HIP(hipMemcpy(c.d_w4, arr4.data(), arr4.size() * 2, hipMemcpyHostToDevice));
+        if (precision_ == IRE_PRECISION_FP8) {
+            // the same slabs as OCP e4m3 with one scale per OUTPUT channel: w_q = e4m3(w / s_w[co]), s_w[co] = max|w[co]| / 448
+            // (the whole e4m3 range per channel); activations are scaled by kActScale = 16 while staging (conv_w4.hip), so the
+            // kernel's accumulator times oscale = s_w / 16 is the conv output and its accumulators start at bias / oscale
+            const float kActScale = 16.0f;
+            std::vector<float> sw(cout), osc(cout), b8(cout);
+            for (int co = 0; co < cout; ++co) {
+                float m = 0.f;
+                for (size_t k = 0; k < (size_t)cin * 9; ++k) m = std::max(m, std::fabs(W[(size_t)co * cin * 9 + k]));
+                sw[co] = m > 0.f ? m / 448.0f : 1.0f;
+                osc[co] = sw[co] / kActScale;
+                b8[co] = bi->second.second[co] / osc[co];
+            }
+            std::vector<unsigned char> arr8((size_t)nb4 * nk4 * 18 * 128 * 8, 0);
+            for (int nb = 0; nb < nb4; ++nb)
+                for (int kc = 0; kc < nk4; ++kc)
+                    for (int kk = 0; kk < 18; ++kk) {
+                        const int tap = kk >> 1, c8 = kk & 1;
+                        for (int n = 0; n < 128; ++n)
+                            for (int e = 0; e < 8; ++e) {
+                                const int co = nb * 128 + perm(n), ci = kc * 16 + c8 * 8 + e;
+                                arr8[((((size_t)nb * nk4 + kc) * 18 + kk) * 128 + n) * 8 + e] = f32_to_e4m3(W[((size_t)co * cin + ci) * 9 + tap] / sw[co]);
+                            }
+                    }
+            c.d_w8 = (unsigned char*)dalloc(arr8.size());
+            c.d_oscale = (float*)dalloc(cout * 4);
+            c.d_bias8 = (float*)dalloc(cout * 4);
+            net_.allocs.push_back(c.d_w8); net_.allocs.push_back(c.d_oscale); net_.allocs.push_back(c.d_bias8);
+            IRE_HIP(hipMemcpy(c.d_w8, arr8.data(), arr8.size(), hipMemcpyHostToDevice));
+            IRE_HIP(hipMemcpy(c.d_oscale, osc.data(), cout * 4, hipMemcpyHostToDevice));
+            IRE_HIP(hipMemcpy(c.d_bias8, b8.data(), cout * 4, hipMemcpyHostToDevice));
+        }
     }
     std::vector<float> bias(cout_pad, 0.f);
     std::memcpy(bias.data(), bi->second.second.data(), sizeof(float) * cout);
@@ -647,6 +701,9 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     }
     if (w4) {
         a.w = cw.d_w4; a.nkc = cw.cin / 16; a.nblocks = cw.cout / 128;
+        if (cw.d_w8 != nullptr && a.ab != nullptr) {      // IRE_PRECISION_FP8: e4m3 operands for the C >= 128 ResBlock convs
+            a.fp8 = 1; a.w = reinterpret_cast<const unsigned short*>(cw.d_w8); a.bias = cw.d_bias8; a.oscale = cw.d_oscale;
+        }
         conv_w4_launch(cw.kind == CONV_RB2, a, R.stream);
     } else if (up_rb) { if (cw.d_wp) a.w = cw.d_wp; conv_up_launch(a, R.stream); }
     else if (rb && rb_tile_h_ == kRbTileH) { if (cw.d_wp) a.w = cw.d_wp; conv_rb_launch(cw.kind == CONV_RB2, /*fused_act=*/a.ab != nullptr, a, R.stream); }

@@ -29,6 +29,9 @@ struct ConvW {
     unsigned short* d_w = nullptr;
     unsigned short* d_wp = nullptr;   // slabs with permuted cout rows for conv_rb.hip's direct epilogue
     unsigned short* d_w4 = nullptr;  // second arrangement for conv_w4.hip (C >= 128 ResBlock convs): 16-channel stages, 128-cout blocks
+    unsigned char* d_w8 = nullptr;   // IRE_PRECISION_FP8: the conv_w4 slabs as OCP e4m3, one scale per output channel
+    float* d_oscale = nullptr;       // [cout] weight scale / activation scale (accumulator -> output)
+    float* d_bias8 = nullptr;        // [cout] bias / oscale (the accumulators start at it)
     float* d_bias = nullptr;
 };
 struct GNW {
@@ -186,6 +189,7 @@ private:
     int max_batch_ = 8;
     int num_lanes_ = 1;
     uint32_t flags_ = 0;
+    int precision_ = IRE_PRECISION_BF16;
     int w4_fused_min_c_ = 128;      // IRE_W4_FUSED_MINC: ResBlock convs with fused activation and cout >= this run on conv_w4's fused variant
     int w4_waves_ = 8;            // IRE_W4_WAVES=4: the one-wave-per-SIMD form, pre-activated inputs only (fused activation needs the 8-wave form)
     int use_w4_ = 1;              // C >= 128 ResBlock convs on conv_w4.hip (IRE_W4=0: conv_rb.hip; IRE_W4_WAVES=4|8)

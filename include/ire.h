@@ -50,7 +50,10 @@ typedef enum ire_status {
     IRE_ERR_INTERNAL = 4
 } ire_status;
 
-enum { IRE_PRECISION_BF16 = 0, IRE_PRECISION_FP8 = 1 /* reserved: rejected in this ABI version */ };
+/* BF16: bf16 storage and MFMA operands, fp32 accumulate.  FP8 (cfg 4 of BASELINE.json): the C >= 128 ResBlock convolutions
+ * take OCP e4m3 MFMA operands -- weights quantised per output channel at load, activations while staging -- everything
+ * else as BF16; stated tolerance vs the fp32 oracle: max |d| <= 6/255, PSNR >= 38 dB. */
+enum { IRE_PRECISION_BF16 = 0, IRE_PRECISION_FP8 = 1 };
 
 /* Score order = the object-literal order of classifier.js:62-70. */
 enum { IRE_SCORE_BLUR = 0, IRE_SCORE_NOISE, IRE_SCORE_LOWLIGHT, IRE_SCORE_COMPRESSION,
@@ -61,7 +64,7 @@ typedef struct ire_engine ire_engine;
 typedef struct ire_config {
     uint32_t struct_size;     /* = sizeof(ire_config); lets the struct grow              */
     int32_t device_index;     /* HIP device ordinal (one engine = one GPU = one process) */
-    int32_t precision;        /* IRE_PRECISION_BF16                                      */
+    int32_t precision;        /* IRE_PRECISION_BF16 | IRE_PRECISION_FP8                  */
     int32_t max_batch;        /* images per call, 1..64 (default 8 when 0)               */
     int32_t num_streams;      /* images restored concurrently on separate HIP streams
                                  (default 0 = engine's choice)                           */

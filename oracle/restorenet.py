@@ -15,6 +15,11 @@ Two modes:
                               outputs, residual sums, the activated conv inputs) so that a layer-
                               by-layer comparison only sees accumulation-order noise -- used to
                               localise indexing bugs that an end-to-end tolerance could hide.
+  restore(..., emulate_bf16=True, emulate_fp8=True)
+                              additionally quantises the two MFMA operands of every C >= 128 ResBlock
+                              convolution the way IRE_PRECISION_FP8 does (csrc/conv_w4.hip, engine.cpp):
+                              weights to OCP e4m3 with one scale per output channel (max|w| -> 448),
+                              the activated input to e4m3 after a x16 scale, clamped at 448.
 """
 import numpy as np
 import torch
@@ -29,10 +34,18 @@ def _bf16(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
 
+FP8_ACT_SCALE = 16.0
+
+
+def _e4m3(t):
+    return torch.clamp(t, -448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
+
+
 class _Net:
-    def __init__(self, weights, emulate_bf16=False, capture=None):
+    def __init__(self, weights, emulate_bf16=False, capture=None, emulate_fp8=False):
         self.w = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in weights.items()}
         self.emu = emulate_bf16
+        self.fp8 = emulate_fp8
         self.cap = capture
 
     def q(self, t):
@@ -60,16 +73,24 @@ class _Net:
         a = rg * (1.0 + s)
         bb = (b[None, :] - mean * rg) * (1.0 + s) + t
         y = x * a[:, :, None, None] + bb[:, :, None, None]
+        if self.fp8 and c >= 128:          # the activated operand goes to e4m3 (x16), not to bf16
+            return _e4m3(F.silu(y) * FP8_ACT_SCALE) / FP8_ACT_SCALE
         return self.q(F.silu(y))
 
-    def conv(self, x, name, stride=1, pad=1):
-        y = F.conv2d(x, self.w[name + ".w"], self.w[name + ".b"], stride=stride, padding=pad)
+    def conv(self, x, name, stride=1, pad=1, fp8=False):
+        w = self.w[name + ".w"]
+        if fp8:
+            sw = w.abs().amax(dim=(1, 2, 3), keepdim=True) / 448.0
+            sw = torch.where(sw > 0, sw, torch.ones_like(sw))
+            w = _e4m3(w / sw) * sw
+        y = F.conv2d(x, w, self.w[name + ".b"], stride=stride, padding=pad)
         return self.q(y)
 
     def resblock(self, x, prefix, level, film):
-        h = self.conv(self.gn_film_silu(x, prefix + ".gn1", level, film), prefix + ".conv1")
+        f8 = self.fp8 and x.shape[1] >= 128
+        h = self.conv(self.gn_film_silu(x, prefix + ".gn1", level, film), prefix + ".conv1", fp8=f8)
         self.keep(prefix + ".h", h)
-        y = self.conv(self.gn_film_silu(h, prefix + ".gn2", level, film), prefix + ".conv2")
+        y = self.conv(self.gn_film_silu(h, prefix + ".gn2", level, film), prefix + ".conv2", fp8=f8)
         out = self.q(y + x)
         self.keep(prefix, out)
         return out
@@ -109,7 +130,7 @@ class _Net:
         return out.permute(0, 2, 3, 1).contiguous().to(torch.uint8).numpy()
 
 
-def restore(rgb_u8, scores, weights, emulate_bf16=False, capture=None, threads=None):
+def restore(rgb_u8, scores, weights, emulate_bf16=False, capture=None, threads=None, emulate_fp8=False):
     """rgb_u8 [N,H,W,3] uint8, scores [N,7] -> restored [N,H,W,3] uint8."""
     rgb_u8 = np.asarray(rgb_u8)
     if rgb_u8.ndim == 3:
@@ -117,4 +138,4 @@ def restore(rgb_u8, scores, weights, emulate_bf16=False, capture=None, threads=N
     if threads:
         torch.set_num_threads(int(threads))
     with torch.no_grad():
-        return _Net(weights, emulate_bf16, capture).forward(rgb_u8, np.asarray(scores).reshape(rgb_u8.shape[0], 7))
+        return _Net(weights, emulate_bf16, capture, emulate_fp8).forward(rgb_u8, np.asarray(scores).reshape(rgb_u8.shape[0], 7))

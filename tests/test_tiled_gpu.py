@@ -98,3 +98,53 @@ def test_two_ranks_exchange_halos_and_partials_bit_identical():
     got = np.concatenate([res[0][1], res[1][1]], axis=0)
     assert got.shape == whole.shape == (h, w, 3)
     assert np.array_equal(got, whole), int(np.abs(got.astype(int) - whole.astype(int)).max())
+
+
+# ---- IRE_PRECISION_FP8 (cfg 4's "fp8 conv MFMA"): OCP e4m3 operands for the C >= 128 ResBlock convolutions --------------------
+FP8_MAX_LSB, FP8_MIN_PSNR = 6, 38.0       # stated tolerance vs the fp32 oracle
+
+
+@pytest.fixture(scope="module")
+def engine_fp8():
+    from image_restoration_platform_amd.engine import Engine
+    eng = Engine(device_index=0, max_batch=8, precision="fp8")
+    yield eng
+    eng.close()
+
+
+@pytest.mark.parametrize("h,w,n", [(64, 96, 2), (72, 136, 1), (256, 256, 1)])
+def test_fp8_meets_the_stated_tolerance_and_tracks_the_fp8_oracle(engine, engine_fp8, weights0, h, w, n):
+    from oracle import classifier as oc
+    from oracle import restorenet as onet
+    imgs = synth.batch(n, h, w, start=5)
+    sc = np.stack([oc.classify(im, True)[0] for im in imgs])
+    engine_fp8.debug_capture(True)
+    try:
+        out = engine_fp8.restore(imgs, scores=sc)
+        cap = {}
+        emu = onet.restore(imgs, sc, weights0, emulate_bf16=True, emulate_fp8=True, capture=cap)
+        # layer by layer against the oracle that quantises the same operands the same way: only accumulation-order / rounding-flip noise
+        for nm in [f"{p}.rb{i}{s}" for p in ("enc2", "enc3", "dec2") for i in range(2) for s in (".h", "")] + ["mid.rb0.h", "mid.rb0", "mid.rb1"]:
+            a, r = engine_fp8.activation(nm), cap[nm].reshape(-1)
+            rel = np.abs(a - r).mean() / (np.abs(r).mean() + 1e-9)
+            assert rel < 0.03, (nm, rel)
+    finally:
+        engine_fp8.debug_capture(False)
+    ref = onet.restore(imgs, sc, weights0)                    # the fp32 function
+    d = np.abs(out.astype(np.int32) - ref.astype(np.int32))
+    mse = float(np.mean((out.astype(np.float64) - ref.astype(np.float64)) ** 2))
+    psnr = 10 * np.log10(255.0 ** 2 / max(mse, 1e-12))
+    assert d.max() <= FP8_MAX_LSB and psnr >= FP8_MIN_PSNR, (int(d.max()), psnr)
+    assert np.abs(out.astype(np.int32) - emu.astype(np.int32)).max() <= 2
+    # it IS a different arithmetic: not bit-identical to the bf16 engine, but close to it
+    b = engine.restore(imgs, scores=sc)
+    assert not np.array_equal(b, out) and np.abs(b.astype(np.int32) - out.astype(np.int32)).max() <= FP8_MAX_LSB
+
+
+def test_fp8_tiled_equals_fp8_untiled(engine_fp8):
+    import torch
+    img = torch.from_numpy(synth.batch(1, 512, 256, start=9)[0]).cuda()
+    whole = engine_fp8.restore_tensor(img[None])[0].clone()
+    tiled = engine_fp8.restore_tiled_tensor(img, 4)
+    torch.cuda.synchronize()
+    assert torch.equal(tiled, whole)
