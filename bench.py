@@ -213,7 +213,7 @@ def run_restore(ctx, eng):
         return
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     f3, f1 = weights.conv_flops(S, S)
-    res = line(ctx, "restored images/sec @%dx%d bs=%d" % (S, S, B), ctx.world * a.steps * B / dt, dt, "bf16", {
+    res = line(ctx, "restored images/sec @%dx%d bs=%d" % (S, S, B), ctx.world * a.steps * B / dt, dt, a.precision, {
         "workload": "%dx%d RGB u8, batch %d per GPU: fused classifier scan + RestoreNet-v0 (43 convs, %.1f GFLOP/image), "
                     "seeded random-init weights" % (S, S, B, (f3 + f1) / 1e9),
         "global_batch": B * ctx.world, "parallelism": "per-image data parallel x%d, no collective" % ctx.world, "streams": a.streams},
