@@ -24,6 +24,7 @@ SOURCES = [
      (["-DIRE_RB_SLOT=" + os.environ["IRE_RB_SLOT"]] if os.environ.get("IRE_RB_SLOT") else [])),
     ("conv_w4.hip", (["-DIRE_W4_STAMPS"] if os.environ.get("IRE_RB_ABLATE") else []) +
      (["-DIRE_W4_TICKS"] if os.environ.get("IRE_RB_ABLATE") == "2" else [])),
+    ("conv_up.hip", []),
     ("gn.hip", []),
     ("fusion.hip", []),
     ("preprocess.hip", []),

@@ -68,6 +68,9 @@ bool conv_rb_permuted_rows();
 // One-wave-per-SIMD variant for C >= 128 ResBlock convs on a pre-activated input (conv_w4.hip):
 // a.nkc = Cin/16, a.nblocks = cout/128, a.w = slabs [nblock][kc16][tap*2 + c8][128][8], 16x32 tiles.
 void conv_w4_launch(bool resid, const ConvArgs& a, hipStream_t stream);
+// CONV_UP as a sub-pixel convolution on the low-resolution grid (conv_up.hip): 4 output parities x 2x2 pre-summed taps.
+// a.Hin/Win = low-res source, a.Hout/Wout = 2x; a.nkc = Cin/32 (even), a.nblocks = cout/32, tiles of 16x32 LOW-res pixels.
+void conv_up_subpixel_launch(const ConvArgs& a, hipStream_t stream);
 // CONV_UP through the same pipelined kernel (Hin/Win = low-res source, Hout/Wout = 2x; a.stats = nullptr).
 void conv_up_launch(const ConvArgs& a, hipStream_t stream);
 

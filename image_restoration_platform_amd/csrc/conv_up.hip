@@ -1,0 +1,286 @@
+// conv_up.hip -- the decoder's "nearest x2 -> 3x3 conv" (RestoreNet-v0 `up` layers, 15 % of the network's FLOPs) as a
+// SUB-PIXEL convolution on the low-resolution grid, gfx950.
+//
+// A 3x3 convolution of a nearest-x2 upsampled tensor reads, for the output pixel (2Y + a, 2X + b), only a 2x2 window of
+// low-resolution pixels: rows Y-1+a .. Y+a, columns X-1+b .. X+b.  The taps that fall on the same low-resolution pixel can be
+// summed ahead of time:   a = 0: row Y-1 <- ky 0,  row Y <- ky 1 + ky 2;     a = 1: row Y <- ky 0 + ky 1,  row Y+1 <- ky 2
+// (same for the columns), so each of the four output parities (a, b) is a 2x2 convolution with its own pre-summed weights
+// (engine.cpp::make_conv builds them; zero padding at the image border carries over exactly because a summed pair never
+// straddles the border).  K per output drops from 9*Cin to 4*Cin: 2.25x fewer MFMAs for the same result, the upsampled
+// tensor never exists, and one staged low-resolution tile serves 4x as many output pixels.
+//
+// Schedule: the persistent, software-pipelined structure of conv_rb.hip (one 512-thread workgroup per CU, 32-channel K
+// stages double-buffered in LDS, input register-prefetched two stages ahead, weights by LDS-DMA, one barrier per stage).
+// Work item = (16x32 LOW-resolution tile, 32-cout block) -> a 32x64 block of output pixels, all four parities: wave w owns
+// low-res rows 2w, 2w+1 and keeps 4 parities x 2 rows x 32 couts = 128 accumulators.  Per stage a tap's two pixel fragments
+// are read once and feed every parity whose window contains the tap: 36 + 32 fragment reads for 64 MFMAs.
+// Roofline: MFMA (2*9*Cin*Cout algorithmic flop per OUTPUT pixel; executed: 2*4*Cin*Cout).
+#include "conv_mfma.hpp"
+
+namespace ire {
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int UP_THREADS = 512;
+constexpr int UP_TH = 16, UP_TW = 32;                 // low-resolution tile
+constexpr int UP_IH = UP_TH + 2, UP_IW = UP_TW + 2;
+constexpr int UP_IN_CHUNKS = UP_IH * UP_IW * 4;        // 2448 x 16 B (32 channels per pixel)
+constexpr int UP_IN_ITERS = (UP_IN_CHUNKS + UP_THREADS - 1) / UP_THREADS;   // 5
+constexpr int UP_IN_BYTES = UP_IN_ITERS * UP_THREADS * 16;                  // 40960: all 5 x 512 chunk slots exist
+constexpr int UP_NT = 32;                             // couts per item
+constexpr int UP_W_CHUNKS = 4 * 16 * UP_NT;           // [parity][kk = tap4*4 + c8][32 rows] x 16 B = 32 KB per stage
+constexpr int UP_W_BYTES = UP_W_CHUNKS * 16;
+constexpr int UP_W_ITERS = UP_W_CHUNKS / UP_THREADS;   // 4
+constexpr int UP_BUF = UP_IN_BYTES + UP_W_BYTES;
+constexpr int UP_LDS = 2 * UP_BUF + 256 * 4;
+
+__device__ __forceinline__ unsigned up_pack(float a, float b) {
+    f32x2_t f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_t));
+}
+// LDS-DMA (see conv_rb.hip::rb_glds16): invisible to the compiler's s_waitcnt bookkeeping, the caller waits and barriers
+__device__ __forceinline__ void up_glds16(const void* gsrc, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+
+struct UpItem { int img, ty, tx, nb; };
+struct UpRegs { uint4 v[UP_IN_ITERS]; unsigned ok; };
+
+__global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[UP_LDS];
+    const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int c8_fixed = tid & 3;
+
+    // ---- persistent work assignment, XCD-aware (as conv_rb.hip) --------------------------------------------------
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int items = tiles_per_img * a.nimg * a.nblocks;
+    const int G = gridDim.x;
+    const int X = G < 8 ? G : 8;
+    const int xcd = blockIdx.x % X, jx = blockIdx.x / X;
+    const int nwx = (G - xcd + X - 1) / X;
+    const int lo = (int)((long long)items * xcd / X), hi = (int)((long long)items * (xcd + 1) / X);
+    const int my_items = (lo + jx < hi) ? (hi - lo - jx + nwx - 1) / nwx : 0;
+    const int nkc = a.nkc;                               // 32-channel stages per item (>= 2)
+    const int S = my_items * nkc;
+    if (S == 0) return;
+
+    struct StageInfo { UpItem it; int kc; };
+    auto decode = [&](int s) -> StageInfo {
+        const int k = s / nkc;
+        const int L = lo + jx + k * nwx;
+        StageInfo si;
+        si.it.nb = L % a.nblocks;
+        const int t = L / a.nblocks;
+        si.it.img = t / tiles_per_img;
+        const int tile = t - si.it.img * tiles_per_img;
+        si.it.ty = tile / a.tiles_x;
+        si.it.tx = tile - si.it.ty * a.tiles_x;
+        si.kc = s - k * nkc;
+        return si;
+    };
+    StageInfo sq0 = decode(0), sq1 = decode(min(1, S - 1)), sq2 = decode(min(2, S - 1));
+
+    const int Cin = a.cin0;
+    const int cin_shift = 31 - __builtin_clz(Cin);
+
+    // per-lane LDS offsets of the 18 (row m, tap) pixel fragments: p = (2*wave + m + ky)*IW + r + kx,
+    // 16-B chunk index p*4 + (c8 ^ ((p>>2)&3)), c8 = 2*(k-step & 1) + h  (the k-step parity toggles bit 5)
+    int a_off[2][9];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int p = (wave * 2 + m + ky) * UP_IW + r + kx;
+            a_off[m][tap] = (p * 4 + (h ^ ((p >> 2) & 3))) * 16;
+        }
+    const int b_off = (h * UP_NT + r) * 16;               // + ((parity*16 + tap4*4 + 2*c8pair) * 32) * 16
+
+    auto load_stage = [&](const StageInfo& si, UpRegs& R) {
+        const UpItem& it = si.it;
+        const int oy1 = it.ty * UP_TH - 1, ox1 = it.tx * UP_TW - 1;
+        const char* base = reinterpret_cast<const char*>(a.in0) + (size_t)it.img * a.in_rows * a.Win * Cin * 2 + si.kc * 64;
+        const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, a.in_rows * a.Win * Cin * 2 - si.kc * 64, 0x00020000);
+        R.ok = 0;
+        int t2 = tid;
+        asm volatile("" : "+v"(t2));
+#pragma unroll
+        for (int i = 0; i < UP_IN_ITERS; ++i) {
+            const int p = (t2 + i * UP_THREADS) >> 2;
+            const int py = p / UP_IW, px = p - py * UP_IW;
+            const int iy = oy1 + py, ix = ox1 + px;
+            const bool ok = (unsigned)(iy - a.iy_lo) < (unsigned)a.iy_span && (unsigned)ix < (unsigned)a.Win;
+            const unsigned off = ok ? ((unsigned)((iy + a.in_row_off) * a.Win + ix) << (cin_shift + 1)) + (unsigned)(c8_fixed * 16) : 0xffffffffu;
+            const u32x4_t lv = __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, 0);      // out of range reads as zero: the padding
+            R.v[i] = make_uint4(lv.x, lv.y, lv.z, lv.w);
+            R.ok |= ok ? (1u << i) : 0u;
+        }
+    };
+    auto store_chunk = [&](int i, const UpRegs& R, uint4* lds_in) {
+        int t2 = tid;
+        asm volatile("" : "+v"(t2));
+        const int idx = t2 + i * UP_THREADS;
+        const bool ok = (R.ok >> i) & 1u;
+        uint4 o;
+        o.x = ok ? R.v[i].x : 0u; o.y = ok ? R.v[i].y : 0u; o.z = ok ? R.v[i].z : 0u; o.w = ok ? R.v[i].w : 0u;
+        const int p = idx >> 2;
+        lds_in[p * 4 + (c8_fixed ^ ((p >> 2) & 3))] = o;
+    };
+    auto wslab = [&](const StageInfo& si) -> const unsigned char* {
+        return reinterpret_cast<const unsigned char*>(a.w) + ((size_t)si.it.nb * nkc + si.kc) * UP_W_BYTES;
+    };
+
+    f32x16_t acc[4][2];
+    const float* bias_lds = reinterpret_cast<const float*>(smem + 2 * UP_BUF);
+    UpRegs R0, R1;
+
+    // ---- epilogue: accumulator i of lane (r, h) of parity (pa, pb), row m is output pixel (2*(ty*16 + 2*wave + m) + pa,
+    // 2*(tx*32 + r) + pb), cout nb*32 + 16*(i>>3) + 8h + (i&7) (permuted slab rows): two 16-B stores per (parity, m) ------------
+    auto epilogue = [&](const UpItem& it) __attribute__((always_inline)) {
+        int r_e = r, h_e = h, w_e = wave;
+        asm volatile("" : "+v"(r_e), "+v"(h_e), "+v"(w_e));
+        char* obase = reinterpret_cast<char*>(a.out) + (size_t)it.img * a.Hout * a.Wout * a.cout * 2;
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.Hout * a.Wout * a.cout * 2, 0x00020000);
+        const int ly = it.ty * UP_TH + w_e * 2, lx = it.tx * UP_TW + r_e;       // low-res coordinates of row m = 0
+#pragma unroll
+        for (int par = 0; par < 4; ++par) {
+            const int pa = par >> 1, pb = par & 1;
+            const int ox = 2 * lx + pb;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int oy = 2 * (ly + m) + pa;
+                const bool inb = oy < a.Hout && ox < a.Wout;
+                const unsigned off = ((unsigned)((oy * a.Wout + ox) * a.cout + it.nb * UP_NT) << 1) + (unsigned)(h_e * 16);
+                const f32x16_t& c = acc[par][m];
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    const u32x4_t wv4 = {up_pack(c[8 * pp + 0], c[8 * pp + 1]), up_pack(c[8 * pp + 2], c[8 * pp + 3]),
+                                         up_pack(c[8 * pp + 4], c[8 * pp + 5]), up_pack(c[8 * pp + 6], c[8 * pp + 7])};
+                    __builtin_amdgcn_raw_buffer_store_b128(wv4, orsrc, inb ? off + (unsigned)(pp * 32) : 0xffffffffu, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int par = 0; par < 4; ++par)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) asm volatile("" : "=v"(acc[par][m]));     // dead until the next item
+    };
+
+    // ---- one pipeline stage ------------------------------------------------------------------------------------------
+    auto stage = [&](int s, auto par_tag) {
+        constexpr int PAR = decltype(par_tag)::value;
+        const unsigned char* ib = smem + PAR * UP_BUF;
+        uint4* in_nxt = reinterpret_cast<uint4*>(smem + (PAR ^ 1) * UP_BUF);
+        const unsigned char* wb = smem + PAR * UP_BUF + UP_IN_BYTES + b_off;
+        unsigned char* w_nxt = smem + (PAR ^ 1) * UP_BUF + UP_IN_BYTES;
+        UpRegs& Rn = PAR ? R0 : R1;   // holds stage s+1 (loaded during stage s-1)
+        UpRegs& Rf = PAR ? R1 : R0;   // free: receives stage s+2
+#pragma unroll
+        for (int i = 0; i < UP_IN_ITERS; ++i) asm volatile("" : "+v"(Rn.v[i].x), "+v"(Rn.v[i].y), "+v"(Rn.v[i].z), "+v"(Rn.v[i].w));
+        load_stage(sq2, Rf);
+        if (sq0.kc == 0) {                 // new item: the accumulators start at the bias (permuted rows: cout 16*(i>>3) + 8h + (i&7))
+            const float* bl = bias_lds + sq0.it.nb * UP_NT + 8 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bv = *reinterpret_cast<const float4*>(bl + 16 * (q >> 1) + 4 * (q & 1));
+#pragma unroll
+                for (int par = 0; par < 4; ++par)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) { acc[par][m][4 * q + 0] = bv.x; acc[par][m][4 * q + 1] = bv.y; acc[par][m][4 * q + 2] = bv.z; acc[par][m][4 * q + 3] = bv.w; }
+            }
+        }
+        // 18 (tap, channel-pair) groups: the two pixel fragments of a group feed every parity whose 2x2 window holds the tap
+#pragma unroll
+        for (int g = 0; g < 18; ++g) {
+            const int tap = g >> 1, cp = g & 1;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            bf16x8_t af[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                af[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ib + (a_off[m][tap] ^ (cp << 5))));
+#pragma unroll
+            for (int pa = 0; pa < 2; ++pa) {
+                const int dy = ky - pa;
+                if (dy < 0 || dy > 1) continue;
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) {
+                    const int dx = kx - pb;
+                    if (dx < 0 || dx > 1) continue;
+                    const int par = pa * 2 + pb, tap4 = dy * 2 + dx;
+                    const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wb + ((par * 16 + tap4 * 4 + 2 * cp) * UP_NT) * 16));
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[par][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, af[m], acc[par][m], 0, 0, 0);   // D[cout][pixel]
+                }
+            }
+            // stage s+1's input: registers -> the other LDS tile, one chunk after groups 1, 4, 7, 10, 13
+            if (g % 3 == 1 && g / 3 < UP_IN_ITERS) store_chunk(g / 3, Rn, in_nxt);
+            // weight slab of stage s+1 by LDS-DMA into the other buffer, early in the stage
+            if (g == 0) {
+                const unsigned char* ws = wslab(sq1);
+                const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+                const unsigned w_nxt_lds = smem_lds + (unsigned)(w_nxt - smem);
+#pragma unroll
+                for (int i = 0; i < UP_W_ITERS; ++i) {
+                    const int cbase = i * UP_THREADS + wave_u * 64;
+                    up_glds16(ws + (size_t)(cbase + lane) * 16, w_nxt_lds + cbase * 16);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // retire the s+2 prefetch now (oldest in the wave's in-order VMEM queue), then the DMA'd slab, before the stage barrier
+#pragma unroll
+        for (int i = 0; i < UP_IN_ITERS; ++i) asm volatile("" : "+v"(Rf.v[i].x), "+v"(Rf.v[i].y), "+v"(Rf.v[i].z), "+v"(Rf.v[i].w));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (PAR == 1) { if (sq0.kc == nkc - 1) epilogue(sq0.it); }     // nkc is even: items end on odd stages
+        __syncthreads();
+        sq0 = sq1; sq1 = sq2; sq2 = decode(min(s + 3, S - 1));
+    };
+
+    // ---- prologue: stage 0 -> LDS buffer 0, stage 1 -> registers -----------------------------------------------------------
+    {
+        float* bl = reinterpret_cast<float*>(smem + 2 * UP_BUF);
+        if (tid < a.cout && tid < 256) bl[tid] = a.bias[tid];
+        load_stage(sq0, R0);
+        const uint4* ws = reinterpret_cast<const uint4*>(wslab(sq0));
+        uint4* wd = reinterpret_cast<uint4*>(smem + UP_IN_BYTES);
+        for (int i = tid; i < UP_W_CHUNKS; i += UP_THREADS) wd[i] = ws[i];
+        uint4* in0 = reinterpret_cast<uint4*>(smem);
+#pragma unroll
+        for (int i = 0; i < UP_IN_ITERS; ++i) store_chunk(i, R0, in0);
+        load_stage(sq1, R1);
+    }
+    __syncthreads();
+    for (int s = 0; s < S; s += 2) {
+        stage(s, std::integral_constant<int, 0>{});
+        if (s + 1 < S) stage(s + 1, std::integral_constant<int, 1>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may be in flight when the workgroup's LDS is released
+}
+
+}  // namespace
+
+// a.in0 = low-res tensor [nimg][Hin (+halo)][Win][Cin], a.out = [nimg][2*Hin][2*Win][cout]; a.nkc = Cin/32 (even), a.nblocks =
+// cout/32, a.tiles_x/y = low-res tiles of 16x32; a.w = sub-pixel slabs [nblock][kc][parity][kk][32 permuted rows][8]
+void conv_up_subpixel_launch(const ConvArgs& a, hipStream_t stream) {
+    if (a.nkc < 2 || (a.nkc & 1) || a.cout > 256) fail(IRE_ERR_INTERNAL, "internal: conv_up_subpixel shape");
+    const int items = a.tiles_x * a.tiles_y * a.nimg * a.nblocks;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int grid = items < cus ? items : cus;
+    hipLaunchKernelGGL(conv_up_kernel, dim3(grid), dim3(UP_THREADS), 0, stream, a);
+    IRE_HIP(hipGetLastError());
+}
+
+}  // namespace ire

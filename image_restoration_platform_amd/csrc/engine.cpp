@@ -89,6 +89,7 @@ Engine::Engine(const ire_config& cfg) {
     if (const char* v = std::getenv("IRE_W4_WAVES")) w4_waves_ = std::atoi(v) == 4 ? 4 : 8;
     if (const char* v = std::getenv("IRE_W4_FUSED_MINC")) w4_fused_min_c_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_UP_RB_MINC")) up_rb_min_c_ = std::atoi(v);
+    if (const char* v = std::getenv("IRE_UP_SUBPIX")) up_subpixel_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_SLOT_STATS")) slot_stats_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_RB_STAMPS")) {   // diagnostic: "<cout>[r]" = stamp the first such ResBlock conv
         stamps_cout_ = std::atoi(v);
@@ -232,6 +233,32 @@ ConvW Engine::make_conv(ConvKind kind, const std::string& wname, const std::stri
         c.d_wp = (unsigned short*)dalloc(arrp.size() * 2);
         net_.allocs.push_back(c.d_wp);
         IRE_HIP(hipMemcpy(c.d_wp, arrp.data(), arrp.size() * 2, hipMemcpyHostToDevice));
+    }
+    if (kind == CONV_UP && cin % 64 == 0 && cout % 32 == 0) {
+        // conv_up.hip: nearest x2 -> 3x3 == four 2x2 convolutions on the low-res grid, one per output parity (pa, pb); the taps that
+        // land on the same low-res pixel are summed here (fp32), then rounded to bf16:
+        //   pa = 0: window row 0 <- ky 0, row 1 <- ky 1 + ky 2;   pa = 1: row 0 <- ky 0 + ky 1, row 1 <- ky 2   (columns alike)
+        const int nbu = cout / 32, nku = cin / 32;
+        std::vector<unsigned short> arru((size_t)nbu * nku * 4 * 16 * 32 * 8, 0);
+        auto lo_of = [](int par, int d) { return par == 0 ? (d == 0 ? 0 : 1) : (d == 0 ? 0 : 2); };
+        auto hi_of = [](int par, int d) { return par == 0 ? (d == 0 ? 0 : 2) : (d == 0 ? 1 : 2); };
+        for (int nb = 0; nb < nbu; ++nb)
+            for (int kc = 0; kc < nku; ++kc)
+                for (int par = 0; par < 4; ++par)
+                    for (int kk = 0; kk < 16; ++kk) {
+                        const int pa = par >> 1, pb = par & 1, tap4 = kk >> 2, c8 = kk & 3, dy = tap4 >> 1, dx = tap4 & 1;
+                        for (int n = 0; n < 32; ++n)
+                            for (int e = 0; e < 8; ++e) {
+                                const int co = nb * 32 + perm(n), ci = kc * 32 + c8 * 8 + e;
+                                float sum = 0.f;
+                                for (int ky = lo_of(pa, dy); ky <= hi_of(pa, dy); ++ky)
+                                    for (int kx = lo_of(pb, dx); kx <= hi_of(pb, dx); ++kx) sum += W[((size_t)co * cin + ci) * 9 + ky * 3 + kx];
+                                arru[(((((size_t)nb * nku + kc) * 4 + par) * 16 + kk) * 32 + n) * 8 + e] = f32_to_bf16(sum);
+                            }
+                    }
+        c.d_wu = (unsigned short*)dalloc(arru.size() * 2);
+        net_.allocs.push_back(c.d_wu);
+        IRE_HIP(hipMemcpy(c.d_wu, arru.data(), arru.size() * 2, hipMemcpyHostToDevice));
     }
     if ((kind == CONV_RB1 || kind == CONV_RB2) && cout >= 128 && cin % 16 == 0 && cout % 128 == 0) {
         // conv_w4.hip slabs: [nblock (128 couts)][kc16][kk = tap*2 + c8][128][8]
@@ -661,8 +688,14 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     a.tiles_x = ceil_div(Wout, 32);
     const bool rb = (cw.kind == CONV_RB1 || cw.kind == CONV_RB2);
     const bool up_rb = (cw.kind == CONV_UP) && rb_tile_h_ == kRbTileH && cw.cout >= up_rb_min_c_;
+    const bool up_sub = up_rb && up_subpixel_ && cw.d_wu != nullptr;       // sub-pixel form: tiles and halo rows on the LOW-res grid
     const int th = (rb || up_rb) ? rb_tile_h_ : conv_tile_h(cw.kind);
     a.tiles_y = ceil_div(Hout, th);
+    if (up_sub) {
+        a.tiles_x = ceil_div(Win, 32); a.tiles_y = ceil_div(Hin, 16);
+        a.iy_lo = (g.halo && g.has_up) ? -1 : 0;
+        a.iy_span = Hin + ((g.halo && g.has_down) ? 1 : 0) - a.iy_lo;
+    }
     a.stats = nullptr;
     if (op.stats_out) {
         // partials are indexed by the GLOBAL tile: a strip writes its tiles at its offset (strip starts are multiples of the
@@ -705,7 +738,8 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
             a.fp8 = 1; a.w = reinterpret_cast<const unsigned short*>(cw.d_w8); a.bias = cw.d_bias8; a.oscale = cw.d_oscale;
         }
         conv_w4_launch(cw.kind == CONV_RB2, a, R.stream);
-    } else if (up_rb) { if (cw.d_wp) a.w = cw.d_wp; conv_up_launch(a, R.stream); }
+    } else if (up_sub) { a.w = cw.d_wu; a.nkc = cw.cin / 32; a.nblocks = cw.cout / 32; conv_up_subpixel_launch(a, R.stream); }
+    else if (up_rb) { if (cw.d_wp) a.w = cw.d_wp; conv_up_launch(a, R.stream); }
     else if (rb && rb_tile_h_ == kRbTileH) { if (cw.d_wp) a.w = cw.d_wp; conv_rb_launch(cw.kind == CONV_RB2, /*fused_act=*/a.ab != nullptr, a, R.stream); }
     else conv_launch(cw.kind, a, R.stream);
     prof_end(R.stream);

@@ -29,6 +29,7 @@ struct ConvW {
     unsigned short* d_w = nullptr;
     unsigned short* d_wp = nullptr;   // slabs with permuted cout rows for conv_rb.hip's direct epilogue
     unsigned short* d_w4 = nullptr;  // second arrangement for conv_w4.hip (C >= 128 ResBlock convs): 16-channel stages, 128-cout blocks
+    unsigned short* d_wu = nullptr;  // CONV_UP as a sub-pixel conv (conv_up.hip): [nblock32][kc32][parity][kk][32][8], taps pre-summed per parity
     unsigned char* d_w8 = nullptr;   // IRE_PRECISION_FP8: the conv_w4 slabs as OCP e4m3, one scale per output channel
     float* d_oscale = nullptr;       // [cout] weight scale / activation scale (accumulator -> output)
     float* d_bias8 = nullptr;        // [cout] bias / oscale (the accumulators start at it)
@@ -193,6 +194,7 @@ private:
     int w4_fused_min_c_ = 128;      // IRE_W4_FUSED_MINC: ResBlock convs with fused activation and cout >= this run on conv_w4's fused variant
     int w4_waves_ = 8;            // IRE_W4_WAVES=4: the one-wave-per-SIMD form, pre-activated inputs only (fused activation needs the 8-wave form)
     int use_w4_ = 1;              // C >= 128 ResBlock convs on conv_w4.hip (IRE_W4=0: conv_rb.hip; IRE_W4_WAVES=4|8)
+    int up_subpixel_ = 1;         // `up` convs as sub-pixel convolutions on the low-res grid (IRE_UP_SUBPIX=0: nearest x2 + 3x3 on conv_rb.hip)
     int up_rb_min_c_ = 32;        // `up` convs with cout >= this run on conv_rb.hip (IRE_UP_RB_MINC), the rest on the v1 kernel
     int slot_stats_ = 0;          // IRE_SLOT_STATS=1: per-workgroup GroupNorm partials at C = 32 (+2 % throughput, gives up bit-identity across batch compositions)
     int prio_young_ = 0;          // static s_setprio for waves 4-7 of conv_rb (A/B'd: it only swaps which half waits)
