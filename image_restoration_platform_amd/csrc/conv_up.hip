@@ -52,7 +52,7 @@ __device__ __forceinline__ void up_glds16(const void* gsrc, unsigned lds_dst_uni
 }
 
 struct UpItem { int img, ty, tx, nb; };
-struct UpRegs { uint4 v[UP_IN_ITERS]; unsigned ok; };
+struct UpRegs { uint4 v[UP_IN_ITERS]; };
 
 __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[UP_LDS];
@@ -107,35 +107,31 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
         }
     const int b_off = (h * UP_NT + r) * 16;               // + ((parity*16 + tap4*4 + 2*c8pair) * 32) * 16
 
-    auto load_stage = [&](const StageInfo& si, UpRegs& R) {
+    auto load_chunk = [&](const StageInfo& si, int i, UpRegs& R) {
         const UpItem& it = si.it;
         const int oy1 = it.ty * UP_TH - 1, ox1 = it.tx * UP_TW - 1;
         const char* base = reinterpret_cast<const char*>(a.in0) + (size_t)it.img * a.in_rows * a.Win * Cin * 2 + si.kc * 64;
         const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, a.in_rows * a.Win * Cin * 2 - si.kc * 64, 0x00020000);
-        R.ok = 0;
         int t2 = tid;
         asm volatile("" : "+v"(t2));
+        const int p = (t2 + i * UP_THREADS) >> 2;
+        const int py = p / UP_IW, px = p - py * UP_IW;
+        const int iy = oy1 + py, ix = ox1 + px;
+        const bool ok = (unsigned)(iy - a.iy_lo) < (unsigned)a.iy_span && (unsigned)ix < (unsigned)a.Win;
+        const unsigned off = ok ? ((unsigned)((iy + a.in_row_off) * a.Win + ix) << (cin_shift + 1)) + (unsigned)(c8_fixed * 16) : 0xffffffffu;
+        const u32x4_t lv = __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, 0);      // out of range reads as zero: the padding
+        R.v[i] = make_uint4(lv.x, lv.y, lv.z, lv.w);
+    };
+    auto load_stage = [&](const StageInfo& si, UpRegs& R) {
 #pragma unroll
-        for (int i = 0; i < UP_IN_ITERS; ++i) {
-            const int p = (t2 + i * UP_THREADS) >> 2;
-            const int py = p / UP_IW, px = p - py * UP_IW;
-            const int iy = oy1 + py, ix = ox1 + px;
-            const bool ok = (unsigned)(iy - a.iy_lo) < (unsigned)a.iy_span && (unsigned)ix < (unsigned)a.Win;
-            const unsigned off = ok ? ((unsigned)((iy + a.in_row_off) * a.Win + ix) << (cin_shift + 1)) + (unsigned)(c8_fixed * 16) : 0xffffffffu;
-            const u32x4_t lv = __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, 0);      // out of range reads as zero: the padding
-            R.v[i] = make_uint4(lv.x, lv.y, lv.z, lv.w);
-            R.ok |= ok ? (1u << i) : 0u;
-        }
+        for (int i = 0; i < UP_IN_ITERS; ++i) load_chunk(si, i, R);
     };
     auto store_chunk = [&](int i, const UpRegs& R, uint4* lds_in) {
         int t2 = tid;
         asm volatile("" : "+v"(t2));
         const int idx = t2 + i * UP_THREADS;
-        const bool ok = (R.ok >> i) & 1u;
-        uint4 o;
-        o.x = ok ? R.v[i].x : 0u; o.y = ok ? R.v[i].y : 0u; o.z = ok ? R.v[i].z : 0u; o.w = ok ? R.v[i].w : 0u;
         const int p = idx >> 2;
-        lds_in[p * 4 + (c8_fixed ^ ((p >> 2) & 3))] = o;
+        lds_in[p * 4 + (c8_fixed ^ ((p >> 2) & 3))] = R.v[i];       // a pixel outside the image was an out-of-range load: already zero
     };
     auto wslab = [&](const StageInfo& si) -> const unsigned char* {
         return reinterpret_cast<const unsigned char*>(a.w) + ((size_t)si.it.nb * nkc + si.kc) * UP_W_BYTES;
@@ -143,7 +139,7 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
 
     f32x16_t acc[4][2];
     const float* bias_lds = reinterpret_cast<const float*>(smem + 2 * UP_BUF);
-    UpRegs R0, R1;
+    UpRegs R;          // one register set: holds stage s+1's input; chunk i goes to LDS and is reloaded with stage s+2 in place
 
     // ---- epilogue: accumulator i of lane (r, h) of parity (pa, pb), row m is output pixel (2*(ty*16 + 2*wave + m) + pa,
     // 2*(tx*32 + r) + pb), cout nb*32 + 16*(i>>3) + 8h + (i&7) (permuted slab rows): two 16-B stores per (parity, m) ------------
@@ -178,55 +174,73 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
     };
 
     // ---- one pipeline stage ------------------------------------------------------------------------------------------
-    auto stage = [&](int s, auto par_tag) {
+    auto init_acc = [&](int nb) {            // new item: the accumulators start at the bias (permuted rows: cout 16*(i>>3) + 8h + (i&7))
+        const float* bl = bias_lds + nb * UP_NT + 8 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bv = *reinterpret_cast<const float4*>(bl + 16 * (q >> 1) + 4 * (q & 1));
+#pragma unroll
+            for (int par = 0; par < 4; ++par)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) { acc[par][m][4 * q + 0] = bv.x; acc[par][m][4 * q + 1] = bv.y; acc[par][m][4 * q + 2] = bv.z; acc[par][m][4 * q + 3] = bv.w; }
+        }
+    };
+    auto stage = [&](int s, auto par_tag, auto last_tag) {
         constexpr int PAR = decltype(par_tag)::value;
+        constexpr bool LAST = decltype(last_tag)::value;      // the item's last stage: epilogue before the barrier
         const unsigned char* ib = smem + PAR * UP_BUF;
         uint4* in_nxt = reinterpret_cast<uint4*>(smem + (PAR ^ 1) * UP_BUF);
         const unsigned char* wb = smem + PAR * UP_BUF + UP_IN_BYTES + b_off;
         unsigned char* w_nxt = smem + (PAR ^ 1) * UP_BUF + UP_IN_BYTES;
-        UpRegs& Rn = PAR ? R0 : R1;   // holds stage s+1 (loaded during stage s-1)
-        UpRegs& Rf = PAR ? R1 : R0;   // free: receives stage s+2
+        // R (stage s+1's input) was retired by the vmcnt(0) that ended the previous stage: say so, or hipcc re-waits with a short count
 #pragma unroll
-        for (int i = 0; i < UP_IN_ITERS; ++i) asm volatile("" : "+v"(Rn.v[i].x), "+v"(Rn.v[i].y), "+v"(Rn.v[i].z), "+v"(Rn.v[i].w));
-        load_stage(sq2, Rf);
-        if (sq0.kc == 0) {                 // new item: the accumulators start at the bias (permuted rows: cout 16*(i>>3) + 8h + (i&7))
-            const float* bl = bias_lds + sq0.it.nb * UP_NT + 8 * h;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 bv = *reinterpret_cast<const float4*>(bl + 16 * (q >> 1) + 4 * (q & 1));
-#pragma unroll
-                for (int par = 0; par < 4; ++par)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) { acc[par][m][4 * q + 0] = bv.x; acc[par][m][4 * q + 1] = bv.y; acc[par][m][4 * q + 2] = bv.z; acc[par][m][4 * q + 3] = bv.w; }
-            }
-        }
-        // 18 (tap, channel-pair) groups: the two pixel fragments of a group feed every parity whose 2x2 window holds the tap
-#pragma unroll
-        for (int g = 0; g < 18; ++g) {
-            const int tap = g >> 1, cp = g & 1;
-            const int ky = tap / 3, kx = tap - ky * 3;
-            bf16x8_t af[2];
+        for (int i = 0; i < UP_IN_ITERS; ++i) asm volatile("" : "+v"(R.v[i].x), "+v"(R.v[i].y), "+v"(R.v[i].z), "+v"(R.v[i].w));
+        // 18 (tap, channel-pair) groups: the two pixel fragments of a group feed every parity whose 2x2 window holds the tap.
+        // Fragment reads run one group ahead of the MFMAs (two register sets), as in conv_rb.hip.
+        bf16x8_t afr[2][2], bfr[2][4];
+        auto read_group = [&](auto g_tag, bf16x8_t (&af)[2], bf16x8_t (&bf)[4]) __attribute__((always_inline)) {
+            constexpr int g = decltype(g_tag)::value;
+            constexpr int tap = g >> 1, cp = g & 1, ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
             for (int m = 0; m < 2; ++m)
                 af[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ib + (a_off[m][tap] ^ (cp << 5))));
+            int n = 0;
 #pragma unroll
-            for (int pa = 0; pa < 2; ++pa) {
-                const int dy = ky - pa;
-                if (dy < 0 || dy > 1) continue;
+            for (int pa = 0; pa < 2; ++pa)
 #pragma unroll
                 for (int pb = 0; pb < 2; ++pb) {
-                    const int dx = kx - pb;
-                    if (dx < 0 || dx > 1) continue;
+                    const int dy = ky - pa, dx = kx - pb;
+                    if (dy < 0 || dy > 1 || dx < 0 || dx > 1) continue;
                     const int par = pa * 2 + pb, tap4 = dy * 2 + dx;
-                    const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wb + ((par * 16 + tap4 * 4 + 2 * cp) * UP_NT) * 16));
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) acc[par][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, af[m], acc[par][m], 0, 0, 0);   // D[cout][pixel]
+                    bf[n++] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wb + ((par * 16 + tap4 * 4 + 2 * cp) * UP_NT) * 16));
                 }
-            }
-            // stage s+1's input: registers -> the other LDS tile, one chunk after groups 1, 4, 7, 10, 13
-            if (g % 3 == 1 && g / 3 < UP_IN_ITERS) store_chunk(g / 3, Rn, in_nxt);
+        };
+        auto mfma_group = [&](auto g_tag, const bf16x8_t (&af)[2], const bf16x8_t (&bf)[4]) __attribute__((always_inline)) {
+            constexpr int g = decltype(g_tag)::value;
+            constexpr int tap = g >> 1, ky = tap / 3, kx = tap - ky * 3;
+            int n = 0;
+#pragma unroll
+            for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) {
+                    const int dy = ky - pa, dx = kx - pb;
+                    if (dy < 0 || dy > 1 || dx < 0 || dx > 1) continue;
+                    const int par = pa * 2 + pb;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[par][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[n], af[m], acc[par][m], 0, 0, 0);   // D[cout][pixel]
+                    ++n;
+                }
+        };
+        auto group = [&](auto g_tag) __attribute__((always_inline)) {
+            constexpr int g = decltype(g_tag)::value;
+            if constexpr (g + 1 < 18) read_group(std::integral_constant<int, g + 1>{}, afr[(g + 1) & 1], bfr[(g + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);       // keep the reads AHEAD of this group's MFMAs
+            mfma_group(g_tag, afr[g & 1], bfr[g & 1]);
+            // stage s+1's input: registers -> the other LDS tile, and the same registers reloaded with stage s+2, in groups 0..4:
+            // the reloads then have 13 groups of MFMAs (~3000 cycles) before the stage's one vmcnt(0)
+            if constexpr (g < UP_IN_ITERS) { store_chunk(g, R, in_nxt); load_chunk(sq2, g, R); }
             // weight slab of stage s+1 by LDS-DMA into the other buffer, early in the stage
-            if (g == 0) {
+            if constexpr (g == 0) {
                 const unsigned char* ws = wslab(sq1);
                 const int wave_u = __builtin_amdgcn_readfirstlane(wave);
                 const unsigned w_nxt_lds = smem_lds + (unsigned)(w_nxt - smem);
@@ -237,12 +251,17 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-        }
-        // retire the s+2 prefetch now (oldest in the wave's in-order VMEM queue), then the DMA'd slab, before the stage barrier
-#pragma unroll
-        for (int i = 0; i < UP_IN_ITERS; ++i) asm volatile("" : "+v"(Rf.v[i].x), "+v"(Rf.v[i].y), "+v"(Rf.v[i].z), "+v"(Rf.v[i].w));
+        };
+        read_group(std::integral_constant<int, 0>{}, afr[0], bfr[0]);
+        group(std::integral_constant<int, 0>{}); group(std::integral_constant<int, 1>{}); group(std::integral_constant<int, 2>{});
+        group(std::integral_constant<int, 3>{}); group(std::integral_constant<int, 4>{}); group(std::integral_constant<int, 5>{});
+        group(std::integral_constant<int, 6>{}); group(std::integral_constant<int, 7>{}); group(std::integral_constant<int, 8>{});
+        group(std::integral_constant<int, 9>{}); group(std::integral_constant<int, 10>{}); group(std::integral_constant<int, 11>{});
+        group(std::integral_constant<int, 12>{}); group(std::integral_constant<int, 13>{}); group(std::integral_constant<int, 14>{});
+        group(std::integral_constant<int, 15>{}); group(std::integral_constant<int, 16>{}); group(std::integral_constant<int, 17>{});
+        // the stage's one wait: the s+2 reloads and the DMA'd slab of s+1 (and the previous item's output stores)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if constexpr (PAR == 1) { if (sq0.kc == nkc - 1) epilogue(sq0.it); }     // nkc is even: items end on odd stages
+        if constexpr (LAST) epilogue(sq0.it);
         __syncthreads();
         sq0 = sq1; sq1 = sq2; sq2 = decode(min(s + 3, S - 1));
     };
@@ -251,19 +270,27 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
     {
         float* bl = reinterpret_cast<float*>(smem + 2 * UP_BUF);
         if (tid < a.cout && tid < 256) bl[tid] = a.bias[tid];
-        load_stage(sq0, R0);
+        load_stage(sq0, R);
         const uint4* ws = reinterpret_cast<const uint4*>(wslab(sq0));
         uint4* wd = reinterpret_cast<uint4*>(smem + UP_IN_BYTES);
         for (int i = tid; i < UP_W_CHUNKS; i += UP_THREADS) wd[i] = ws[i];
         uint4* in0 = reinterpret_cast<uint4*>(smem);
 #pragma unroll
-        for (int i = 0; i < UP_IN_ITERS; ++i) store_chunk(i, R0, in0);
-        load_stage(sq1, R1);
+        for (int i = 0; i < UP_IN_ITERS; ++i) store_chunk(i, R, in0);
+        load_stage(sq1, R);
     }
     __syncthreads();
-    for (int s = 0; s < S; s += 2) {
-        stage(s, std::integral_constant<int, 0>{});
-        if (s + 1 < S) stage(s + 1, std::integral_constant<int, 1>{});
+    // nkc is even: an item starts on an even stage and ends on an odd one; its last stage pair is peeled with the epilogue
+    // (a conditional epilogue inside the loop splits live ranges of in-flight prefetch registers: conv_w4.hip)
+    int s = 0;
+    for (int k = 0; k < my_items; ++k) {
+        init_acc(sq0.it.nb);
+        for (int kc = 0; kc + 2 < nkc; kc += 2) {
+            stage(s, std::integral_constant<int, 0>{}, std::false_type{}); ++s;
+            stage(s, std::integral_constant<int, 1>{}, std::false_type{}); ++s;
+        }
+        stage(s, std::integral_constant<int, 0>{}, std::false_type{}); ++s;
+        stage(s, std::integral_constant<int, 1>{}, std::true_type{}); ++s;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may be in flight when the workgroup's LDS is released
 }
