@@ -18,10 +18,7 @@ SOURCES = [
     ("classifier.hip", ["-ffp-contract=off"]),
     ("conv_mfma.hip", []),
     ("conv_rb.hip", (["-DIRE_RB_ABLATE"] if os.environ.get("IRE_RB_ABLATE") else []) +
-     (["-DIRE_RB_DEFER=" + os.environ["IRE_RB_DEFER"]] if os.environ.get("IRE_RB_DEFER") else []) +
-     (["-DIRE_RB_NGP64=" + os.environ["IRE_RB_NGP64"]] if os.environ.get("IRE_RB_NGP64") else []) +
-     (["-DIRE_RB_DIRECT=" + os.environ["IRE_RB_DIRECT"]] if os.environ.get("IRE_RB_DIRECT") else []) +
-     (["-DIRE_RB_SLOT=" + os.environ["IRE_RB_SLOT"]] if os.environ.get("IRE_RB_SLOT") else [])),
+     (["-DIRE_RB_NGP64=" + os.environ["IRE_RB_NGP64"]] if os.environ.get("IRE_RB_NGP64") else [])),
     ("conv_w4.hip", (["-DIRE_W4_STAMPS"] if os.environ.get("IRE_RB_ABLATE") else []) +
      (["-DIRE_W4_TICKS"] if os.environ.get("IRE_RB_ABLATE") == "2" else [])),
     ("conv_up.hip", []),
@@ -82,6 +79,7 @@ def build(force=False, verbose=False):
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
     build_node_addon()
+    build_torch_extension()
     if verbose:
         print("built", LIB)
     return LIB
@@ -100,6 +98,27 @@ def build_node_addon():
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("node addon build failed:\n" + r.stderr[-2000:])
+    return out
+
+
+def build_torch_extension():
+    """The PyTorch-ROCm extension host (csrc/torch_ext.cpp -> lib/_ire_torch.so), built in-tree with the include / library
+    paths torch.utils.cpp_extension reports; plain C++ (no device code): g++.  It dlopens libire.so at run time."""
+    src = os.path.join(CSRC, "torch_ext.cpp")
+    out = os.path.join(HERE, "lib", "_ire_torch.so")
+    if os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(src), os.path.getmtime(os.path.join(HERE, "..", "include", "ire.h"))):
+        return out
+    import sysconfig
+    from torch.utils import cpp_extension as ce
+    incs = ce.include_paths() + [sysconfig.get_paths()["include"], "/opt/rocm/include"]
+    libdir = ce.library_paths()[0]
+    cmd = (["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM", "-DTORCH_EXTENSION_NAME=_ire_torch",
+            "-DTORCH_API_INCLUDE_EXTENSION_H", "-D_GLIBCXX_USE_CXX11_ABI=" + str(int(__import__("torch")._C._GLIBCXX_USE_CXX11_ABI))] +
+           ["-isystem" + i for i in incs] + [src, "-o", out, "-L" + libdir, "-Wl,-rpath," + libdir,
+            "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch", "-ltorch_python", "-ldl"])
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("torch extension build failed:\n" + r.stderr[-3000:])
     return out
 
 

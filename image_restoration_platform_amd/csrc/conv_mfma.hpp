@@ -34,7 +34,6 @@ struct ConvArgs {
     int Hin, Win, Hout, Wout, cout;
     int tiles_x, tiles_y, nimg, nblocks;
     int group_size;              // cout / 8
-    int stat_slots;              // 0: stats[nimg][tiles][8][2] per tile; > 0 (= grid size): stats[nimg][slots][8][2], one entry per workgroup
     int prio_young;              // conv_rb: raise the issue priority of waves 4-7
     // Row-strip execution (cfg 4, engine.cpp "strips"): the input tensors of a strip carry `in_row_off` halo rows above local
     // row 0 (and as many below); a (virtual) input row iy of the strip is readable iff iy_lo <= iy < iy_lo + iy_span -- the
@@ -55,16 +54,11 @@ int conv_nsteps(ConvKind kind);       // MFMA k-steps per K-chunk (weight slab =
 void conv_launch(ConvKind kind, const ConvArgs& a, hipStream_t stream);
 
 // Persistent software-pipelined variant for CONV_RB1 / CONV_RB2 (conv_rb.hip): 16x32 tiles
-// (a.tiles_y must be ceil(Hout/16)), same weight slab layout, same ConvArgs.
+// (a.tiles_y must be ceil(Hout/16)), same ConvArgs; the weight slab rows are in permuted cout order (row n of a 32-row tile =
+// cout n with bits 2 and 3 swapped: engine.cpp::make_conv), so the epilogue stores straight from the accumulators.
 constexpr int kRbTileH = 16;
 // fused_act: apply y = silu(x*A+B) while staging (a.ab); otherwise the input is already activated.
 void conv_rb_launch(bool resid, bool fused_act, const ConvArgs& a, hipStream_t stream);
-// Workgroups conv_rb_launch will start for `a` if that instantiation accumulates GroupNorm partials per workgroup
-// (a.stat_slots must then be set to it), else 0 (per-tile partials).
-int conv_rb_stat_slots(bool fused_act, const ConvArgs& a);
-// true when conv_rb.hip was built with the direct epilogue and therefore expects slab rows in permuted cout order
-// (row n of a 32-row tile = cout n with bits 2 and 3 swapped); conv_w4.hip always does.
-bool conv_rb_permuted_rows();
 // One-wave-per-SIMD variant for C >= 128 ResBlock convs on a pre-activated input (conv_w4.hip):
 // a.nkc = Cin/16, a.nblocks = cout/128, a.w = slabs [nblock][kc16][tap*2 + c8][128][8], 16x32 tiles.
 void conv_w4_launch(bool resid, const ConvArgs& a, hipStream_t stream);

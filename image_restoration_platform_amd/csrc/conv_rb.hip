@@ -100,38 +100,12 @@ struct RbCfg {
     // streaming: [in0 | w0][in1 | w1]; resident weights: [in0][in1][w]
     static constexpr int BUF_STRIDE = WRES ? RB_IN_BYTES : RB_IN_BYTES + W_BYTES;
     static constexpr int W_OFF0 = WRES ? 2 * RB_IN_BYTES : RB_IN_BYTES;
-    // WRES (C = 32): [in0][in1][w][O]; O = 32 KB parking space of the previous item's output tile, drained
-    // (residual add, statistics, stores) inside the NEXT stage's MFMA loop ("deferred epilogue").
-#ifndef IRE_RB_DEFER
-#define IRE_RB_DEFER 1
-#endif
-    // DIRECT (default): the epilogue stores straight from the accumulators (v_permlane32_swap pairs the two k-half lanes of a
-    // pixel into 16-B stores): no LDS transpose, no epilogue barriers, a third of the instructions.  IRE_RB_DIRECT=0 keeps the
-    // LDS-transposed (and, at C = 32, deferred) epilogue for A/B runs.
-#ifndef IRE_RB_DIRECT
-#define IRE_RB_DIRECT 1
-#endif
-    static constexpr bool DIRECT = IRE_RB_DIRECT != 0;
-    static constexpr bool DEFER = WRES && (IRE_RB_DEFER != 0) && !DIRECT;
-    // SLOT (C = 32, direct epilogue; build with IRE_RB_SLOT=1, then run-time opt-in through a.stat_slots > 0 / IRE_SLOT_STATS=1): GroupNorm partials stay in per-lane registers
-    // across the workgroup's items and are reduced across lanes / waves only when the image changes (once per kernel at
-    // bs 8): ~130 fewer instructions per item, -30 us per launch.  Opt-in because the fp32 summation order then depends on
-    // how the batch's items were dealt to workgroups: results stay deterministic per call but are no longer bit-identical
-    // across batch compositions (they are with the default per-tile partials + double-precision finalize).
-#ifndef IRE_RB_SLOT
-#define IRE_RB_SLOT 0      // compiled out by default: the run-time dual path costs the default mode 0.8 % (same-box A/B 757 -> 763 img/s)
-#endif
-    static constexpr bool SLOT = DIRECT && WRES && (IRE_RB_SLOT != 0);
-    static constexpr int OUT_TILE_BYTES = RB_TH * RB_TW * NT * 2;
-    static constexpr int O_OFF = 2 * RB_IN_BYTES + W_BYTES;
-    static constexpr int MAIN_BYTES = WRES ? 2 * RB_IN_BYTES + W_BYTES + OUT_TILE_BYTES : 2 * (RB_IN_BYTES + W_BYTES);
+    static constexpr int MAIN_BYTES = WRES ? 2 * RB_IN_BYTES + W_BYTES : 2 * (RB_IN_BYTES + W_BYTES);
     static constexpr int RED_HALF = 8 * (NT / 8) * 4 * 4;     // [8 waves][NT/8 chunks][sA,qA,sB,qB]
     static constexpr int RED_BYTES = 2 * RED_HALF;             // two copies, alternating per item (DIRECT: no barrier before the write)
     static constexpr int COEF_BYTES = 2 * 256;              // two stages x 32 channels x (A,B) floats
     static constexpr int BIAS_BYTES = 256 * 4;              // the layer's whole bias vector (cout <= 256)
     static constexpr int LDS_BYTES = MAIN_BYTES + RED_BYTES + COEF_BYTES + BIAS_BYTES;
-    static constexpr int OUT_ITERS = RB_TH * RB_TW * (NT / 8) / RB_THREADS;    // NT/8
-    static_assert(RB_TH * RB_TW * NT * 2 <= BUF_STRIDE, "output tile must fit in one stage buffer");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
@@ -169,10 +143,6 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
     const int my_items = (lo + jx < hi) ? (hi - lo - jx + nwx - 1) / nwx : 0;
     const int nkc = a.nkc;
     const int S = my_items * nkc;                                // stages this workgroup runs
-    if constexpr (C::SLOT) {      // this workgroup's slot of every image starts at 0 -- also when it has no item at all
-        if (a.stats != nullptr && a.stat_slots > 0)
-            for (int i = tid; i < a.nimg * 16; i += RB_THREADS) a.stats[((size_t)(i >> 4) * a.stat_slots + blockIdx.x) * 16 + (i & 15)] = 0.f;
-    }
     if (S == 0) return;
 
     auto item_of = [&](int k) -> RbItem {                        // k-th item of this workgroup
@@ -363,105 +333,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
     };
 
     // ---- epilogue building blocks ------------------------------------------------------------------------
-    struct DrainStats { float sA, qA, sB, qB; };
-    // out tile [512 px][NT] bf16; 16-B chunk cc of pixel p lives at chunk cc ^ (p & (NCC-1)).  Accumulator i of lane
-    // (r = pixel column, h) is cout j*32 + 8*(i>>2) + 4h + (i&3): 4 consecutive couts -> one 8-byte LDS write.
-    auto acc_to_lds = [&](const RbItem& it, unsigned char* lds_ob) {
-        const int cout0 = it.nb * NT;
-        int r_e = r, h_e = h;
-        asm volatile("" : "+v"(r_e), "+v"(h_e));   // index math recomputed here (hoisted copies were spilled)
-#pragma unroll
-        for (int j = 0; j < NTL; ++j) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 bv = *reinterpret_cast<const float4*>(
-                    reinterpret_cast<const float*>(smem + C::MAIN_BYTES + C::RED_BYTES + C::COEF_BYTES) + cout0 + j * 32 + 8 * q + 4 * h_e);
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const int pix = (wave * 2 + m) * RB_TW + r_e;
-                    const int cc = j * 4 + q;                     // 16-B chunk holding couts 8q..8q+7 of n-tile j
-                    uint2 v;
-                    v.x = rb_pack(acc[m][j][4 * q + 0] + bv.x, acc[m][j][4 * q + 1] + bv.y);
-                    v.y = rb_pack(acc[m][j][4 * q + 2] + bv.z, acc[m][j][4 * q + 3] + bv.w);
-                    *reinterpret_cast<uint2*>(lds_ob + (pix * NCC + (cc ^ (pix & (NCC - 1)))) * 16 + h_e * 8) = v;
-                }
-            }
-        }
-        // the accumulators are dead until the next item zeroes them: tell the register allocator
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int j = 0; j < NTL; ++j) asm volatile("" : "=v"(acc[m][j]));
-    };
-    // residual tile: all loads issued together, addresses clamped into the image (stores are predicated)
-    auto drain_load_resid = [&](const RbItem& it, uint4 (&rv)[C::OUT_ITERS]) {
-        if constexpr (RESID && !(DBG & 4)) {
-            int te = tid;
-            asm volatile("" : "+v"(te));
-            const int cc = te % NCC;
-            const int oy0 = it.ty * RB_TH, ox0 = it.tx * RB_TW, cout0 = it.nb * NT;
-            const char* rbase = reinterpret_cast<const char*>(a.resid) + (size_t)it.img * a.Hout * a.Wout * a.cout * 2;   // uniform
-#pragma unroll
-            for (int k = 0; k < C::OUT_ITERS; ++k) {
-                const int pix = (te + k * RB_THREADS) / NCC;
-                const int oy = min(oy0 + (pix >> 5), a.Hout - 1), ox = min(ox0 + (pix & 31), a.Wout - 1);
-                const unsigned off = ((unsigned)((oy * a.Wout + ox) * a.cout + cout0) << 1) + (unsigned)(cc * 16);
-                rv[k] = *reinterpret_cast<const uint4*>(rbase + off);
-            }
-        }
-    };
-    // one 16-B chunk of the parked tile: + residual, GroupNorm partial sums, full-line store.  Branch-free except
-    // the store predicate (valid = false on the first stage, when nothing is parked yet).
-    auto drain_chunk = [&](int k, const RbItem& it, bool valid, const unsigned char* lds_ob, const uint4 (&rv)[C::OUT_ITERS],
-                           DrainStats& ds) {
-        int te = tid;
-        asm volatile("" : "+v"(te));
-        const int cc = te % NCC;
-        const int oy0 = it.ty * RB_TH, ox0 = it.tx * RB_TW, cout0 = it.nb * NT;
-        const int idx = te + k * RB_THREADS;
-        const int pix = idx / NCC;
-        const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
-        const bool inb = valid && oy < a.Hout && ox < a.Wout;
-        const uint4 o = reinterpret_cast<const uint4*>(lds_ob)[pix * NCC + (cc ^ (pix & (NCC - 1)))];
-        char* obase = reinterpret_cast<char*>(a.out) + (size_t)it.img * a.Hout * a.Wout * a.cout * 2;   // uniform
-        const unsigned off = ((unsigned)((oy * a.Wout + ox) * a.cout + cout0) << 1) + (unsigned)(cc * 16);
-        unsigned w[4] = {o.x, o.y, o.z, o.w};
-        if constexpr (RESID && !(DBG & 4)) {
-            const unsigned rw[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w};
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-                w[d] = rb_pack(rb_lo(w[d]) + rb_lo(rw[d]), rb_hi(w[d]) + rb_hi(rw[d]));
-        }
-        // GroupNorm partial sums of the final bf16 values: v_dot2c_f32_bf16 sums a bf16 pair (x (1,1)) or its squares
-        // (x itself) into fp32 in one instruction; out-of-image pixels (and the empty first stage) are deselected.
-        {
-            const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
-            float ts0 = 0.f, tq0 = 0.f, ts1 = 0.f, tq1 = 0.f;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const bf16x2_t wv = __builtin_bit_cast(bf16x2_t, w[d]);
-                if (d < 2) { ts0 = __builtin_amdgcn_fdot2_f32_bf16(wv, ones, ts0, false); tq0 = __builtin_amdgcn_fdot2_f32_bf16(wv, wv, tq0, false); }
-                else { ts1 = __builtin_amdgcn_fdot2_f32_bf16(wv, ones, ts1, false); tq1 = __builtin_amdgcn_fdot2_f32_bf16(wv, wv, tq1, false); }
-            }
-            ds.sA += inb ? ts0 : 0.f; ds.qA += inb ? tq0 : 0.f;
-            ds.sB += inb ? ts1 : 0.f; ds.qB += inb ? tq1 : 0.f;
-        }
-        if (inb) {
-            if constexpr (DBG & 4) { if (w[0] == 0x12345678u) obase[off] = 1; }
-            else *reinterpret_cast<uint4*>(obase + off) = make_uint4(w[0], w[1], w[2], w[3]);
-        }
-    };
-    auto drain_finish = [&](const RbItem& it, bool valid, DrainStats& ds) {
-        if (!valid) return;                                    // wave-uniform
-        ds.sA = rb_group_sum<NCC>(ds.sA); ds.qA = rb_group_sum<NCC>(ds.qA);
-        ds.sB = rb_group_sum<NCC>(ds.sB); ds.qB = rb_group_sum<NCC>(ds.qB);
-        if (lane < NCC) {
-            float* d = red + (wave * NCC + lane) * 4;
-            d[0] = ds.sA; d[1] = ds.qA; d[2] = ds.sB; d[3] = ds.qB;
-        }
-        st_img = it.img; st_tile = it.tile; st_nb = it.nb;
-    };
-    // ---- direct epilogue (C::DIRECT) ---------------------------------------------------------------------------
+    // ---- epilogue, straight from the accumulators -----------------------------------------------------------------
     // MFMA row rho of lane (r = pixel column, h) is accumulator i with rho = 8*(i>>2) + 4h + (i&3).  The weight slab is stored
     // with its rows permuted (bits 2 and 3 of rho swapped, engine.cpp::make_conv), which makes accumulator i the cout
     // j*32 + 16*(i>>3) + 8h + (i&7): for 16-cout group g = (j, p) a lane owns ONE whole 16-B chunk cc = j*4 + 2p + h of its
@@ -473,47 +345,6 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
 #define IRE_RB_NGP64 4
 #endif
     constexpr int NGP = (NT == 64 && FUSED_ACT) ? IRE_RB_NGP64 : NG;      // residual groups requested a stage ahead
-    float sl[NG][4];                      // SLOT: per-lane running (sA, qA, sB, qB) of chunk j*4 + 2p + h
-#pragma unroll
-    for (int g = 0; g < NG; ++g) sl[g][0] = sl[g][1] = sl[g][2] = sl[g][3] = 0.f;
-    int sl_img = -1;
-    // every wave of the workgroup calls this at the same item boundary (the item sequence is workgroup-uniform)
-    auto slot_flush = [&](int img) __attribute__((always_inline)) {
-        int h_e = h;
-        asm volatile("" : "+v"(h_e));
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float v = rb_swap16_add(rb_ror_add<8>(rb_ror_add<4>(rb_ror_add<2>(rb_ror_add<1>(sl[g][k])))));
-                if ((lane & 31) == 0) red_base[(wave * NCC + (g >> 1) * 4 + 2 * (g & 1) + h_e) * 4 + k] = v;
-                sl[g][k] = 0.f;
-            }
-        }
-        __syncthreads();
-        const int Gs = a.group_size, ngl = NT / Gs;
-        if (tid < ngl) {
-            float s = 0.f, q = 0.f;
-            const int cpg = Gs >> 3;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) {
-                if (Gs == 4) {
-                    const float* d = red_base + (w * NCC + (tid >> 1)) * 4 + 2 * (tid & 1);
-                    s += d[0]; q += d[1];
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (k < cpg) {
-                            const float* d = red_base + (w * NCC + tid * cpg + k) * 4;
-                            s += d[0] + d[2]; q += d[1] + d[3];
-                        }
-                }
-            }
-            float* st = a.stats + (((size_t)img * a.stat_slots + blockIdx.x) * 8 + tid) * 2;     // nblocks == 1 here
-            st[0] = s; st[1] = q;
-        }
-        __syncthreads();
-    };
     uint4 erv[NG][2];
     unsigned eoffs[2];
     bool einb[2];
@@ -553,12 +384,6 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         asm volatile("" : "+v"(h_e));
         const int cout0 = it.nb * NT;
         epi_fetch_rest(it);
-        if constexpr (C::SLOT) {
-            if (a.stats != nullptr && a.stat_slots > 0 && it.img != sl_img) {         // workgroup-uniform
-                if (sl_img >= 0) slot_flush(sl_img);
-                sl_img = it.img;
-            }
-        }
         char* obase = reinterpret_cast<char*>(a.out) + (size_t)it.img * a.Hout * a.Wout * a.cout * 2;
         const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.Hout * a.Wout * a.cout * 2, 0x00020000);
         (void)obase;
@@ -572,20 +397,14 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
             const int g = j * 2 + pp;
             // permuted slab rows (engine.cpp::make_conv): accumulators 8pp .. 8pp+7 of lane-half h are the 8 CONTIGUOUS couts
             // j*32 + 16pp + 8h + (0..7) = 16-B chunk cc = j*4 + 2pp + h of the pixel: pack and store, no lane exchange
-            const float4 b0 = *reinterpret_cast<const float4*>(bias_lds + cout0 + j * 32 + 16 * pp + 8 * h_e);
-            const float4 b1 = *reinterpret_cast<const float4*>(bias_lds + cout0 + j * 32 + 16 * pp + 8 * h_e + 4);
             float sA = 0.f, qA = 0.f, sB = 0.f, qB = 0.f;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const f32x16_t& c = acc[m][j];
                 unsigned x0, x1, y0, y1;
-                if constexpr (C::DIRECT) {      // bias already in the accumulators (they start at it)
-                    x0 = rb_pack(c[8 * pp + 0], c[8 * pp + 1]); x1 = rb_pack(c[8 * pp + 2], c[8 * pp + 3]);
-                    y0 = rb_pack(c[8 * pp + 4], c[8 * pp + 5]); y1 = rb_pack(c[8 * pp + 6], c[8 * pp + 7]);
-                } else {
-                    x0 = rb_pack(c[8 * pp + 0] + b0.x, c[8 * pp + 1] + b0.y); x1 = rb_pack(c[8 * pp + 2] + b0.z, c[8 * pp + 3] + b0.w);
-                    y0 = rb_pack(c[8 * pp + 4] + b1.x, c[8 * pp + 5] + b1.y); y1 = rb_pack(c[8 * pp + 6] + b1.z, c[8 * pp + 7] + b1.w);
-                }
+                // the bias is already in the accumulators (they start at it)
+                x0 = rb_pack(c[8 * pp + 0], c[8 * pp + 1]); x1 = rb_pack(c[8 * pp + 2], c[8 * pp + 3]);
+                y0 = rb_pack(c[8 * pp + 4], c[8 * pp + 5]); y1 = rb_pack(c[8 * pp + 6], c[8 * pp + 7]);
                 unsigned w[4] = {x0, x1, y0, y1};
                 if constexpr (RESID && !(DBG & 4)) {
                     const uint4 rr = erv[g][m];
@@ -609,9 +428,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
                     __builtin_amdgcn_raw_buffer_store_b128(wv4, orsrc, einb[m] ? eoffs[m] + (unsigned)(g * 32) : 0xffffffffu, 0, 0);
                 }
             }
-            if (C::SLOT && a.stat_slots > 0) {
-                sl[g][0] += sA; sl[g][1] += qA; sl[g][2] += sB; sl[g][3] += qB;
-            } else if (!UPS) {        // ResBlock convs always feed a GroupNorm (a.stats != nullptr), `up` convs never do: no run-time branch
+            if (!UPS) {        // ResBlock convs always feed a GroupNorm (a.stats != nullptr), `up` convs never do: no run-time branch
                                       // sum over the 32 lanes of each half (= one chunk each), not across halves
                 // the four chains advance one step at a time, side by side: each DPP then reads a value written three
                 // instructions earlier and needs no s_nop padding (a chain reduced on its own gets one per step)
@@ -639,13 +456,11 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int j = 0; j < NTL; ++j) asm volatile("" : "=v"(acc[m][j]));     // dead until the next item
-        if (!(C::SLOT && a.stat_slots > 0)) { st_img = it.img; st_tile = it.tile; st_nb = it.nb; st_par = red_par; red_par ^= 1; }
+        st_img = it.img; st_tile = it.tile; st_nb = it.nb; st_par = red_par; red_par ^= 1;
     };
-    // WRES + DIRECT (C = 32, one n-tile, nkc == 1): every item's accumulators START at the bias -- 16 registers for the whole
+    // WRES (C = 32, one n-tile, nkc == 1): every item's accumulators START at the bias -- 16 registers for the whole
     // kernel instead of 32 v_add_f32 per item in the epilogue.  Accumulator i of lane (r, h) is cout 16*(i>>3) + 8h + (i&7).
     f32x16_t bias_acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    RbItem pend{0, 0, 0, 0, 0};      // deferred epilogue: the item parked in O
-    bool pend_valid = false;
 
     // ---- one pipeline stage (PAR = s & 1 selects buffers and register sets statically) ---------------
     RbRegs R0, R1;
@@ -670,17 +485,12 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         load_coeffs(s & 1, cA, cB);                 // coefficients of stage s+1's data (slot written last stage)
         float4 cnext = fetch_coeffs(sq2);           // for the data of stage s+2, transformed during stage s+1
         load_stage(sq2, Rf);
-        uint4 drv[C::OUT_ITERS];                    // deferred epilogue: residual of the parked item
-        DrainStats dst{0.f, 0.f, 0.f, 0.f};
-        if constexpr (C::DEFER) drain_load_resid(pend, drv);
-        if constexpr (C::DIRECT) {
-            if constexpr (WRES) epi_prefetch(sq0.it);                       // nkc == 1: every stage ends an item
-            else if constexpr (PAR == 1) { if (sq0.kc == nkc - 1) epi_prefetch(sq0.it); }   // nkc is even: items end on odd stages
-        }
+        if constexpr (WRES) epi_prefetch(sq0.it);                       // nkc == 1: every stage ends an item
+        else if constexpr (PAR == 1) { if (sq0.kc == nkc - 1) epi_prefetch(sq0.it); }   // nkc is even: items end on odd stages
 
         if constexpr (!WRES) {           // WRES (nkc == 1): step 0 accumulates onto the bias registers
             if (sq0.kc == 0) {           // new item (not in the epilogue: 64 dead registers there)
-                if constexpr (C::DIRECT) {
+                {
                     // accumulators start at the bias (permuted rows: accumulator i of lane-half h is cout j*32 + 16(i>>3) + 8h + (i&7)):
                     // 4*NTL LDS reads per item replace 32*NTL epilogue adds; the moves take the place of the zeroing
                     const float* bl = reinterpret_cast<const float*>(smem + C::MAIN_BYTES + C::RED_BYTES + C::COEF_BYTES) + sq0.it.nb * NT + 8 * h;
@@ -692,7 +502,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
 #pragma unroll
                             for (int m = 0; m < 2; ++m) { acc[m][j][4 * q + 0] = bv.x; acc[m][j][4 * q + 1] = bv.y; acc[m][j][4 * q + 2] = bv.z; acc[m][j][4 * q + 3] = bv.w; }
                         }
-                } else zero_acc();
+                }
             }
         }
         // (4) 18 MFMA k-steps from the current buffer, the s+1 transform interleaved between groups
@@ -727,7 +537,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
                     for (int j = 0; j < NTL; ++j)
                     {
                         f32x16_t cin = acc[m][j];
-                        if constexpr (WRES) { if (st == 0) cin = C::DIRECT ? bias_acc : f32x16_t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }
+                        if constexpr (WRES) { if (st == 0) cin = bias_acc; }
                         acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[st & 1][j], afr[st & 1][m], cin, 0, 0, 0);  // D[cout][pixel]
                     }
             } else if constexpr (!(DBG & 2)) {
@@ -739,10 +549,6 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
             {   // piece st of the s+1 transform (chunk st>>2, word st&3)
                 tw[st & 3] = transform_word(word_of(Rn.v[st >> 2], st & 3), st & 3, cA, cB);
                 if ((st & 3) == 3) store_words(st >> 2, Rn, tw, in_nxt);
-            }
-            if constexpr (C::DEFER) {
-                if (st >= 10 && ((st - 10) & 1) == 0 && (st - 10) / 2 < C::OUT_ITERS)
-                    drain_chunk((st - 10) / 2, pend, pend_valid, smem + C::O_OFF, drv, dst);
             }
             if constexpr (!WRES) {
                 // (2) weight slab of stage s+1 by LDS-DMA (global_load_lds_dwordx4: 16 B per lane, no registers), a
@@ -779,46 +585,13 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         stamp(s, 2);
         // (6) last k-chunk of the item: epilogue
         const int kc = sq0.kc;
-        if constexpr (C::DIRECT) {
-            if constexpr (WRES) direct_epilogue(sq0.it);
-            else if constexpr (PAR == 1) { if (kc == nkc - 1) direct_epilogue(sq0.it); }
-        } else if constexpr (C::DEFER) {
-            // every stage ends an item (nkc == 1).  The previous item's tile was drained inside the loop above;
-            // park this item's tile in O for the next stage.
-            drain_finish(pend, pend_valid, dst);
-            __syncthreads();                                   // all drains of O and all reads of buf[cur] are done
-            stamp(s, 3);
-            flush_stats();
-            const RbItem it = sq0.it;
-            acc_to_lds(it, smem + C::O_OFF);
-            pend = it; pend_valid = true;
-        } else if (kc == nkc - 1) {
-            // no priority skew inside the barrier-delimited epilogue (the unprioritised half took 3x longer here)
-            const bool young = a.prio_young && __builtin_amdgcn_readfirstlane(wave) >= 4;
-            if (young) __builtin_amdgcn_s_setprio(0);
-            const RbItem it = sq0.it;
-            uint4 rv[C::OUT_ITERS];
-            drain_load_resid(it, rv);                          // before the barrier: covered by the wait for the slow half
-            __syncthreads();                                   // every wave is done reading buf[cur]
-            stamp(s, 3);
-            flush_stats();                                     // (red[] of the previous item is complete)
-            unsigned char* lds_ob = smem + PAR * C::BUF_STRIDE;  // out tile in buf[cur]
-            acc_to_lds(it, lds_ob);
-            stamp(s, 6);
-            __syncthreads();
-            stamp(s, 7);
-            DrainStats ds{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < C::OUT_ITERS; ++k) drain_chunk(k, it, true, lds_ob, rv, ds);
-            stamp(s, 8);
-            drain_finish(it, true, ds);
-            if (young) __builtin_amdgcn_s_setprio(1);
-        }
+        if constexpr (WRES) direct_epilogue(sq0.it);
+        else if constexpr (PAR == 1) { if (kc == nkc - 1) direct_epilogue(sq0.it); }
         stamp(s, 4);
         // (7) stage barrier: buf[nxt] complete, buf[cur] (and red[]) free
         __syncthreads();
         stamp(s, 5);
-        if constexpr (C::DIRECT) flush_stats();                 // red[st_par] is complete; its next writer is two items away
+        flush_stats();                                          // red[st_par] is complete; its next writer is two items away
         sq0 = sq1; sq1 = sq2; sq2 = decode(min(s + 3, S - 1));
     };
 
@@ -848,7 +621,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         load_stage(sq1, R1);
     }
     __syncthreads();
-    if constexpr (WRES && C::DIRECT) {
+    if constexpr (WRES) {
         const float* bl = reinterpret_cast<const float*>(smem + C::MAIN_BYTES + C::RED_BYTES + C::COEF_BYTES);
 #pragma unroll
         for (int i = 0; i < 16; ++i) bias_acc[i] = bl[16 * (i >> 3) + 8 * h + (i & 7)];     // permuted slab rows
@@ -862,17 +635,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         stage(s, std::integral_constant<int, 0>{});
         if (s + 1 < S) stage(s + 1, std::integral_constant<int, 1>{});
     }
-    if constexpr (C::DEFER) {   // the last item is still parked in O (made visible by the last stage barrier)
-        uint4 drv[C::OUT_ITERS];
-        DrainStats dst{0.f, 0.f, 0.f, 0.f};
-        drain_load_resid(pend, drv);
-#pragma unroll
-        for (int k = 0; k < C::OUT_ITERS; ++k) drain_chunk(k, pend, pend_valid, smem + C::O_OFF, drv, dst);
-        drain_finish(pend, pend_valid, dst);
-        __syncthreads();
-    }
     flush_stats();
-    if constexpr (C::SLOT) { if (a.stats != nullptr && a.stat_slots > 0 && sl_img >= 0) slot_flush(sl_img); }
 }
 
 template <int NT, bool RESID, bool WRES, bool FUSED_ACT, int DBG = 0, bool UPS = false>
@@ -904,18 +667,6 @@ void conv_up_launch(const ConvArgs& a, hipStream_t stream) {
     if (a.cout == 32) launch_rb<32, false, false, false, 0, true>(a, stream);
     else launch_rb<64, false, false, false, 0, true>(a, stream);
 }
-
-int conv_rb_stat_slots(bool fused_act, const ConvArgs& a) {
-    (void)fused_act;
-    if (!(a.cout == 32 && RbCfg<32, false, true, true>::SLOT) || a.stats == nullptr) return 0;
-    const int items = a.tiles_x * a.tiles_y * a.nimg * a.nblocks;
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return items < cus ? items : cus;
-}
-
-bool conv_rb_permuted_rows() { return RbCfg<64, false, false, true>::DIRECT; }
 
 void conv_rb_launch(bool resid, bool fused_act, const ConvArgs& a, hipStream_t stream) {
     if (a.stats == nullptr) fail(IRE_ERR_INTERNAL, "internal: conv_rb_launch needs a GroupNorm partials buffer (ResBlock convs always feed a GroupNorm)");

@@ -90,7 +90,6 @@ Engine::Engine(const ire_config& cfg) {
     if (const char* v = std::getenv("IRE_W4_FUSED_MINC")) w4_fused_min_c_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_UP_RB_MINC")) up_rb_min_c_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_UP_SUBPIX")) up_subpixel_ = std::atoi(v);
-    if (const char* v = std::getenv("IRE_SLOT_STATS")) slot_stats_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_RB_STAMPS")) {   // diagnostic: "<cout>[r]" = stamp the first such ResBlock conv
         stamps_cout_ = std::atoi(v);
         stamps_resid_ = std::strchr(v, 'r') != nullptr;
@@ -224,7 +223,7 @@ ConvW Engine::make_conv(ConvKind kind, const std::string& wname, const std::stri
     // swapped, so that the 16 accumulators of a lane-half are two runs of 8 CONTIGUOUS couts (one 16-B store each, no
     // v_permlane32_swap pairing).  The v1 kernel keeps the natural order (c.d_w).
     auto perm = [](int n) { return (n & ~12) | ((n & 4) << 1) | ((n & 8) >> 1); };
-    if ((kind == CONV_RB1 || kind == CONV_RB2 || kind == CONV_UP) && conv_rb_permuted_rows()) {
+    if (kind == CONV_RB1 || kind == CONV_RB2 || kind == CONV_UP) {
         std::vector<unsigned short> arrp(arr.size(), 0);
         const size_t rows = arr.size() / ((size_t)c.nt * 8);
         for (size_t rr = 0; rr < rows; ++rr)
@@ -707,7 +706,6 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     a.nimg = g.nimg; a.nblocks = cw.nblocks;
     a.group_size = std::max(1, a.cout / 8);
     a.stamps = nullptr;
-    a.stat_slots = 0;
     a.prio_young = prio_young_;
     a.w4_waves = (a.ab == nullptr) ? w4_waves_ : 8;
     if (stamps_dev_ && rb && cw.cout == stamps_cout_ && (cw.kind == CONV_RB2) == stamps_resid_ && !stamps_taken_) {
@@ -728,10 +726,6 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     prof_begin(fam, R.stream, flops, bytes);
     // conv_w4: pre-activated input (ab == nullptr) or, from w4_fused_min_c_ up, activation fused into its staging (8-wave form)
     const bool w4 = rb && rb_tile_h_ == kRbTileH && use_w4_ && cw.d_w4 != nullptr && (a.ab == nullptr || cw.cout >= w4_fused_min_c_);
-    if (slot_stats_ && !w4 && !up_rb && rb && rb_tile_h_ == kRbTileH && a.stats && g.halo == 0) {
-        a.stat_slots = conv_rb_stat_slots(a.ab != nullptr, a);
-        if (a.stat_slots) R.stat_parts = a.stat_slots;
-    }
     if (w4) {
         a.w = cw.d_w4; a.nkc = cw.cin / 16; a.nblocks = cw.cout / 128;
         if (cw.d_w8 != nullptr && a.ab != nullptr) {      // IRE_PRECISION_FP8: e4m3 operands for the C >= 128 ResBlock convs

@@ -196,7 +196,6 @@ private:
     int use_w4_ = 1;              // C >= 128 ResBlock convs on conv_w4.hip (IRE_W4=0: conv_rb.hip; IRE_W4_WAVES=4|8)
     int up_subpixel_ = 1;         // `up` convs as sub-pixel convolutions on the low-res grid (IRE_UP_SUBPIX=0: nearest x2 + 3x3 on conv_rb.hip)
     int up_rb_min_c_ = 32;        // `up` convs with cout >= this run on conv_rb.hip (IRE_UP_RB_MINC), the rest on the v1 kernel
-    int slot_stats_ = 0;          // IRE_SLOT_STATS=1: per-workgroup GroupNorm partials at C = 32 (+2 % throughput, gives up bit-identity across batch compositions)
     int prio_young_ = 0;          // static s_setprio for waves 4-7 of conv_rb (A/B'd: it only swaps which half waits)
     int act_split_min_c_ = 512;  // IRE_ACT_SPLIT_MINC: ResBlock convs with C >= this read a pre-activated tensor (gn_apply_silu pass); none by default (same-box A/B, r01: 128 -> 747, 256 -> 763 img/s; with conv_w4's fused variant from C = 128: 256 -> 796, 512 -> 799.5)
     int rb_tile_h_ = kRbTileH;  // 16: persistent pipelined conv_rb.hip; 8: conv_mfma.hip (IRE_CONV_V1=1)

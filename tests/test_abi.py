@@ -62,3 +62,41 @@ def test_product_package_never_imports_the_oracle():
                 src = open(os.path.join(dp, f), errors="ignore").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "libire_oracle" not in src, f   # never loads the oracle library either
+
+
+def _c_prototypes():
+    """{name: (return kind, [argument kinds])} parsed from include/ire.h; kinds: int, double, size_t, void, string, ptr."""
+    txt = open(os.path.join(ROOT, "include", "ire.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(int|void|size_t|const char\s*\*)\s+(ire_[a-z_0-9]+)\s*\(([^)]*)\)\s*;", txt):
+        ret = "string" if "char" in m.group(1) else m.group(1)
+        args = []
+        for a in [x.strip() for x in m.group(3).split(",") if x.strip() and x.strip() != "void"]:
+            if "*" in a:
+                args.append("string" if re.match(r"const char\s*\*", a) else "ptr")
+            elif a.startswith("double"):
+                args.append("double")
+            elif a.startswith("size_t"):
+                args.append("size_t")
+            else:
+                args.append("int")
+        out[m.group(2)] = (ret, args)
+    return out
+
+
+def test_ffi_napi_binding_declares_every_symbol_with_the_header_signature():
+    """node/ire_ffi.mjs (the ffi-napi binding north_star names) cannot be loaded here (the module is not installable offline):
+    parse its declaration table and hold it to include/ire.h, symbol by symbol."""
+    src = open(os.path.join(ROOT, "image_restoration_platform_amd", "node", "ire_ffi.mjs")).read()
+    decl = {}
+    for m in re.finditer(r"^\s*(ire_[a-z_0-9]+):\s*\['(\w+)',\s*\[([^\]]*)\]\],?\s*$", src, flags=re.M):
+        kinds = []
+        for a in [x.strip() for x in m.group(3).split(",") if x.strip()]:
+            kinds.append({"P": "ptr", "PP": "ptr", "IP": "ptr", "'int'": "int", "'double'": "double", "'size_t'": "size_t", "'string'": "string"}[a])
+        decl[m.group(1)] = (m.group(2), kinds)
+    protos = _c_prototypes()
+    assert sorted(decl) == sorted(protos) == _declared()
+    for name, (ret, args) in protos.items():
+        assert decl[name] == (ret, args), (name, decl[name], (ret, args))
+    assert int(re.search(r"IRE_ABI_VERSION = (\d+)", src).group(1)) == _lib.load().ire_abi_version()

@@ -69,11 +69,11 @@ def test_end_to_end_vs_fp32_oracle(engine, weights0, h, w, n):
 
 
 @pytest.mark.parametrize("env", [{"IRE_W4": "0"}, {"IRE_W4_WAVES": "4", "IRE_ACT_SPLIT_MINC": "128"}, {"IRE_W4_WAVES": "4"}, {"IRE_CONV_V1": "1"}, {"IRE_UP_RB_MINC": "64"},
-                                 {"IRE_ACT_SPLIT_MINC": "64"}, {"IRE_ACT_SPLIT_MINC": "128"}, {"IRE_SLOT_STATS": "1"},
+                                 {"IRE_ACT_SPLIT_MINC": "64"}, {"IRE_ACT_SPLIT_MINC": "128"}, {"IRE_UP_SUBPIX": "0"},
                                  {"IRE_W4_FUSED_MINC": "100000", "IRE_ACT_SPLIT_MINC": "256"}, {"IRE_W4_FUSED_MINC": "100000"}])
 def test_alternate_kernel_schedules_agree(engine, weights0, env, monkeypatch):
     """Every A/B switch of the engine (conv_rb instead of conv_w4 at C >= 128, the 4-wave conv_w4, the v1 conv schedule, the
-    v1 `up` kernel, the separate activation pass from C = 64, per-workgroup GroupNorm partials at C = 32) computes the same network: each meets the oracle bound, and
+    v1 `up` kernel, the separate activation pass from C = 64, nearest x2 + 3x3 instead of the sub-pixel `up` convolution) computes the same network: each meets the oracle bound, and
     differs from the default schedule only through fp32 summation order of the GroupNorm partials (bf16 roundings of
     intermediate activations flip: <= 2 LSB, and only a minority of output samples move at all)."""
     from image_restoration_platform_amd.engine import Engine
