@@ -111,8 +111,12 @@ struct RbCfg {
 
 // DBG (timing ablations only, results are wrong): 1 = no MFMA, 2 = no fragment reads + no MFMA,
 // 4 = no epilogue global traffic, 8 = no input global loads.
-template <int NT, bool RESID, bool WRES, bool FUSED_ACT, int DBG = 0, bool UPS = false>
+// HEAD (NT = 32, weights resident, fused GroupNorm+SiLU): RestoreNet's last layer, 32 -> 3 channels (slab padded to 32 rows):
+// the epilogue is out = clamp(round(input + y)) as u8 RGB -- couts 0..2 are accumulators 0..2 of the lanes with h = 0 -- no
+// bf16 tensor, no statistics.  Same pipeline as every other C = 32 convolution instead of the single-buffered v1 kernel.
+template <int NT, bool RESID, bool WRES, bool FUSED_ACT, int DBG = 0, bool UPS = false, bool HEAD = false>
 __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
+    static_assert(!HEAD || (NT == 32 && WRES && FUSED_ACT && !RESID && !UPS), "HEAD: the C = 32 resident-weight fused variant");
     using C = RbCfg<NT, RESID, WRES, FUSED_ACT>;
     constexpr int NTL = C::NTL;
     constexpr int NCC = NT / 8;
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
     float* red = red_base;
     auto flush_stats = [&]() {
         if (st_img < 0) return;
-        if (UPS || a.stats == nullptr) { st_img = -1; return; }
+        if (UPS || HEAD || a.stats == nullptr) { st_img = -1; return; }
         const float* red = red_base + st_par * (C::RED_HALF / 4);
         if (__builtin_amdgcn_readfirstlane(wave) != 0) { st_img = -1; return; }   // only wave 0 has work: spare the other waves the scalar ladder
         const int Gs = a.group_size, ngl = NT / Gs;
@@ -382,6 +386,27 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
     auto direct_epilogue = [&](const RbItem& it) __attribute__((always_inline)) {
         int h_e = h;
         asm volatile("" : "+v"(h_e));
+        if constexpr (HEAD) {
+            int r_e = r, w_e = wave;
+            asm volatile("" : "+v"(r_e), "+v"(w_e));
+            const int ox = it.tx * RB_TW + r_e;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int oy = it.ty * RB_TH + w_e * 2 + m;
+                if (h_e == 0 && oy < a.Hout && ox < a.Wout) {
+                    const size_t gpx = (((size_t)it.img * a.Hout + oy) * a.Wout + ox) * 3;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        float vv = (float)a.u8_in[gpx + c] + acc[m][0][c];          // the bias is already in the accumulator
+                        vv = fminf(fmaxf(vv, 0.f), 255.f);
+                        a.u8_out[gpx + c] = (unsigned char)(int)floorf(vv + 0.5f);
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) asm volatile("" : "=v"(acc[m][0]));
+            return;
+        }
         const int cout0 = it.nb * NT;
         epi_fetch_rest(it);
         char* obase = reinterpret_cast<char*>(a.out) + (size_t)it.img * a.Hout * a.Wout * a.cout * 2;
@@ -485,7 +510,8 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         load_coeffs(s & 1, cA, cB);                 // coefficients of stage s+1's data (slot written last stage)
         float4 cnext = fetch_coeffs(sq2);           // for the data of stage s+2, transformed during stage s+1
         load_stage(sq2, Rf);
-        if constexpr (WRES) epi_prefetch(sq0.it);                       // nkc == 1: every stage ends an item
+        if constexpr (HEAD) {}                                          // the head's epilogue reads 3 input bytes per pixel itself
+        else if constexpr (WRES) epi_prefetch(sq0.it);                  // nkc == 1: every stage ends an item
         else if constexpr (PAR == 1) { if (sq0.kc == nkc - 1) epi_prefetch(sq0.it); }   // nkc is even: items end on odd stages
 
         if constexpr (!WRES) {           // WRES (nkc == 1): step 0 accumulates onto the bias registers
@@ -638,14 +664,14 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
     flush_stats();
 }
 
-template <int NT, bool RESID, bool WRES, bool FUSED_ACT, int DBG = 0, bool UPS = false>
+template <int NT, bool RESID, bool WRES, bool FUSED_ACT, int DBG = 0, bool UPS = false, bool HEAD = false>
 void launch_rb(const ConvArgs& a, hipStream_t stream) {
     const int items = a.tiles_x * a.tiles_y * a.nimg * a.nblocks;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int grid = items < cus ? items : cus;
-    hipLaunchKernelGGL((conv_rb_kernel<NT, RESID, WRES, FUSED_ACT, DBG, UPS>), dim3(grid), dim3(RB_THREADS), 0, stream, a);
+    hipLaunchKernelGGL((conv_rb_kernel<NT, RESID, WRES, FUSED_ACT, DBG, UPS, HEAD>), dim3(grid), dim3(RB_THREADS), 0, stream, a);
     IRE_HIP(hipGetLastError());
 }
 
@@ -666,6 +692,11 @@ void conv_up_launch(const ConvArgs& a, hipStream_t stream) {
     // nearest x2 -> conv3x3 (2C -> C): weights streamed (nkc >= 2), no prologue, no residual, no statistics
     if (a.cout == 32) launch_rb<32, false, false, false, 0, true>(a, stream);
     else launch_rb<64, false, false, false, 0, true>(a, stream);
+}
+
+void conv_head_launch(const ConvArgs& a, hipStream_t stream) {
+    if (a.cout != 32 || a.nkc != 1 || a.nblocks != 1 || !a.ab || !a.u8_in || !a.u8_out) fail(IRE_ERR_INTERNAL, "internal: conv_head_launch arguments");
+    launch_rb<32, false, true, true, 0, false, true>(a, stream);
 }
 
 void conv_rb_launch(bool resid, bool fused_act, const ConvArgs& a, hipStream_t stream) {

@@ -90,6 +90,7 @@ Engine::Engine(const ire_config& cfg) {
     if (const char* v = std::getenv("IRE_W4_FUSED_MINC")) w4_fused_min_c_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_UP_RB_MINC")) up_rb_min_c_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_UP_SUBPIX")) up_subpixel_ = std::atoi(v);
+    if (const char* v = std::getenv("IRE_HEAD_RB")) head_rb_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_RB_STAMPS")) {   // diagnostic: "<cout>[r]" = stamp the first such ResBlock conv
         stamps_cout_ = std::atoi(v);
         stamps_resid_ = std::strchr(v, 'r') != nullptr;
@@ -223,7 +224,7 @@ ConvW Engine::make_conv(ConvKind kind, const std::string& wname, const std::stri
     // swapped, so that the 16 accumulators of a lane-half are two runs of 8 CONTIGUOUS couts (one 16-B store each, no
     // v_permlane32_swap pairing).  The v1 kernel keeps the natural order (c.d_w).
     auto perm = [](int n) { return (n & ~12) | ((n & 4) << 1) | ((n & 8) >> 1); };
-    if (kind == CONV_RB1 || kind == CONV_RB2 || kind == CONV_UP) {
+    if (kind == CONV_RB1 || kind == CONV_RB2 || kind == CONV_UP || kind == CONV_HEAD) {
         std::vector<unsigned short> arrp(arr.size(), 0);
         const size_t rows = arr.size() / ((size_t)c.nt * 8);
         for (size_t rr = 0; rr < rows; ++rr)
@@ -688,7 +689,8 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     const bool rb = (cw.kind == CONV_RB1 || cw.kind == CONV_RB2);
     const bool up_rb = (cw.kind == CONV_UP) && rb_tile_h_ == kRbTileH && cw.cout >= up_rb_min_c_;
     const bool up_sub = up_rb && up_subpixel_ && cw.d_wu != nullptr;       // sub-pixel form: tiles and halo rows on the LOW-res grid
-    const int th = (rb || up_rb) ? rb_tile_h_ : conv_tile_h(cw.kind);
+    const bool head_rb = cw.kind == CONV_HEAD && rb_tile_h_ == kRbTileH && head_rb_ && cw.d_wp != nullptr;    // the head on the pipelined kernel
+    const int th = (rb || up_rb || head_rb) ? rb_tile_h_ : conv_tile_h(cw.kind);
     a.tiles_y = ceil_div(Hout, th);
     if (up_sub) {
         a.tiles_x = ceil_div(Win, 32); a.tiles_y = ceil_div(Hin, 16);
@@ -732,7 +734,8 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
             a.fp8 = 1; a.w = reinterpret_cast<const unsigned short*>(cw.d_w8); a.bias = cw.d_bias8; a.oscale = cw.d_oscale;
         }
         conv_w4_launch(cw.kind == CONV_RB2, a, R.stream);
-    } else if (up_sub) { a.w = cw.d_wu; a.nkc = cw.cin / 32; a.nblocks = cw.cout / 32; conv_up_subpixel_launch(a, R.stream); }
+    } else if (head_rb) { a.w = cw.d_wp; conv_head_launch(a, R.stream); }
+    else if (up_sub) { a.w = cw.d_wu; a.nkc = cw.cin / 32; a.nblocks = cw.cout / 32; conv_up_subpixel_launch(a, R.stream); }
     else if (up_rb) { if (cw.d_wp) a.w = cw.d_wp; conv_up_launch(a, R.stream); }
     else if (rb && rb_tile_h_ == kRbTileH) { if (cw.d_wp) a.w = cw.d_wp; conv_rb_launch(cw.kind == CONV_RB2, /*fused_act=*/a.ab != nullptr, a, R.stream); }
     else conv_launch(cw.kind, a, R.stream);

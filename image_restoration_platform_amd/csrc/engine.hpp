@@ -194,6 +194,7 @@ private:
     int w4_fused_min_c_ = 128;      // IRE_W4_FUSED_MINC: ResBlock convs with fused activation and cout >= this run on conv_w4's fused variant
     int w4_waves_ = 8;            // IRE_W4_WAVES=4: the one-wave-per-SIMD form, pre-activated inputs only (fused activation needs the 8-wave form)
     int use_w4_ = 1;              // C >= 128 ResBlock convs on conv_w4.hip (IRE_W4=0: conv_rb.hip; IRE_W4_WAVES=4|8)
+    int head_rb_ = 1;             // the 32 -> 3 head conv on conv_rb.hip's pipelined kernel (IRE_HEAD_RB=0: the v1 kernel)
     int up_subpixel_ = 1;         // `up` convs as sub-pixel convolutions on the low-res grid (IRE_UP_SUBPIX=0: nearest x2 + 3x3 on conv_rb.hip)
     int up_rb_min_c_ = 32;        // `up` convs with cout >= this run on conv_rb.hip (IRE_UP_RB_MINC), the rest on the v1 kernel
     int prio_young_ = 0;          // static s_setprio for waves 4-7 of conv_rb (A/B'd: it only swaps which half waits)
