@@ -2,6 +2,7 @@
 import collections, csv, glob, sys
 
 src, dst = sys.argv[1], sys.argv[2]
+title = sys.argv[3] if len(sys.argv) > 3 else "Round 1"
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 dur = collections.defaultdict(float)
 n = collections.defaultdict(int)
@@ -10,7 +11,7 @@ for p in sorted(glob.glob(src + "/p*/r_counter_collection.csv")):
     for r in csv.DictReader(open(p)):
         k = r["Kernel_Name"]
         k = k[k.find("conv_"):] if "conv_" in k else k[k.rfind("::") + 2:]
-        k = k[:66]
+        k = k[:72]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         seen[k][r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     if p.endswith("p1/r_counter_collection.csv"):
@@ -31,8 +32,8 @@ for k, c in agg.items():
                  100.0 * c.get("SQ_LDS_BANK_CONFLICT", 0) / max(c.get("SQ_LDS_IDX_ACTIVE", 1), 1),
                  100.0 * c.get("SQ_WAIT_INST_ANY", 0) / max(c.get("SQ_WAVE_CYCLES", 1), 1)))
 with open(dst, "w") as f:
-    f.write("# Round 1 — PMC counters per kernel, default bench step (1024x1024 bs 8)\n\n"
-            "`tools/pmc_util.sh`: four separate `rocprofv3 --pmc` passes of `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile`\n"
+    f.write("# " + title + " — PMC counters per kernel, default bench step (1024x1024 bs 8)\n\n"
+            "four separate `rocprofv3 --pmc` passes of `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile`\n"
             "(2 steps traced; no trace domain combined with `--pmc`).  `MfmaUtil` = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs):\n"
             "the counter equals #MFMA x 32 cycles exactly (checked against the launch's FLOPs), so this is the achieved fraction of the MFMA\n"
             "pipe AT THE CLOCK THE KERNEL RAN AT (column GHz; profiled passes run a few % slower than unprofiled ones).\n"

@@ -26,7 +26,7 @@ def stats(src, dst, title, footer=""):
 
 
 def is_conv3x3(name):
-    if "conv_rb_kernel" in name or "conv_w4_kernel" in name:
+    if "conv_rb_kernel" in name or "conv_w4_kernel" in name or "conv_up_kernel" in name:
         return True
     if "conv_mfma_kernel<4, 9," in name and not name.rstrip().endswith("true>(ire::ConvArgs)"):   # last arg = HEAD: its own family
         return True
@@ -50,7 +50,7 @@ def traffic(fetch_csv, write_csv, dst, steps):
     out = {
         "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile",
         "unit_note": "counters are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); WRITE_SIZE as is",
-        "family": "conv3x3 (conv_rb_kernel + conv_w4_kernel, all instantiations, + the stride-2 conv_mfma_kernel instantiation)",
+        "family": "conv3x3 (conv_rb_kernel + conv_w4_kernel + conv_up_kernel, all instantiations, + the stride-2 conv_mfma_kernel instantiation)",
         "per_kernel": {},
     }
     tot_f = tot_w = 0.0
