@@ -16,6 +16,7 @@
 //   * C = 32: the whole 18 KB weight set stays resident in LDS for the life of the workgroup.
 // Roofline: MFMA for C >= 128 (2*9*C*C flop per pixel), HBM for C = 32/64 (4C..6C B per pixel).
 #include "conv_mfma.hpp"
+#include "persist.hpp"
 
 #include <cstdlib>
 
@@ -82,9 +83,7 @@ template <int NCC> __device__ __forceinline__ float rb_group_sum(float v) {
     return rb_swap32_add(v);
 }
 
-struct RbItem {
-    int img, ty, tx, nb, tile;  // tile = ty*tiles_x + tx
-};
+using RbItem = PersistItem;   // img, ty, tx, nb, tile = ty*tiles_x + tx
 
 struct RbRegs {          // one prefetched input stage
     uint4 v[RB_IN_ITERS];
@@ -136,42 +135,15 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         }
     };
 
-    // ---- persistent work assignment (XCD-aware: blocks b and b+8 share an XCD / L2) ----------------
+    // ---- persistent work assignment (persist.hpp: XCD-aware, advanced by additions instead of per-stage divisions) ----
     const int tiles_per_img = a.tiles_x * a.tiles_y;
-    const int items = tiles_per_img * a.nimg * a.nblocks;
-    const int G = gridDim.x;
-    const int X = G < 8 ? G : 8;
-    const int xcd = blockIdx.x % X, jx = blockIdx.x / X;
-    const int nwx = (G - xcd + X - 1) / X;                       // workgroups in this XCD group
-    const int lo = (int)((long long)items * xcd / X), hi = (int)((long long)items * (xcd + 1) / X);
-    const int my_items = (lo + jx < hi) ? (hi - lo - jx + nwx - 1) / nwx : 0;
+    PersistCursor cursor(a.tiles_x, a.tiles_y, a.nimg, a.nblocks, a.nkc);
     const int nkc = a.nkc;
-    const int S = my_items * nkc;                                // stages this workgroup runs
+    const int S = cursor.S;                                      // stages this workgroup runs
     if (S == 0) return;
-
-    auto item_of = [&](int k) -> RbItem {                        // k-th item of this workgroup
-        const int L = lo + jx + k * nwx;
-        RbItem it;
-        it.nb = L % a.nblocks;
-        const int t = L / a.nblocks;
-        it.img = t / tiles_per_img;
-        it.tile = t - it.img * tiles_per_img;
-        it.ty = it.tile / a.tiles_x;
-        it.tx = it.tile - it.ty * a.tiles_x;
-        return it;
-    };
-
-    // Stage descriptors are decoded ONCE per stage (three integer divisions) and kept in a 3-deep queue:
-    // sq0 = stage s (MFMA + epilogue), sq1 = stage s+1 (weights), sq2 = stage s+2 (prefetch, coefficients).
-    struct StageInfo { RbItem it; int kc; };
-    auto decode = [&](int s) -> StageInfo {
-        const int k = s / nkc;
-        StageInfo si;
-        si.it = item_of(k);
-        si.kc = s - k * nkc;
-        return si;
-    };
-    StageInfo sq0 = decode(0), sq1 = decode(min(1, S - 1)), sq2 = decode(min(2, S - 1));
+    // sq0 = stage s (MFMA + epilogue), sq1 = stage s+1 (weights), sq2 = stage s+2 (prefetch, coefficients)
+    using StageInfo = PersistStage;
+    StageInfo sq0 = cursor.cur, sq1 = cursor.next(), sq2 = cursor.next();
 
     const unsigned short* src = reinterpret_cast<const unsigned short*>(a.in0);
     const int Cin = a.cin0;
@@ -618,7 +590,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         __syncthreads();
         stamp(s, 5);
         flush_stats();                                          // red[st_par] is complete; its next writer is two items away
-        sq0 = sq1; sq1 = sq2; sq2 = decode(min(s + 3, S - 1));
+        sq0 = sq1; sq1 = sq2; sq2 = cursor.next();
     };
 
     // ---- prologue: stage 0 into buffer 0, stage 1 into registers --------------------------------------

@@ -16,6 +16,7 @@
 // are read once and feed every parity whose window contains the tap: 36 + 32 fragment reads for 64 MFMAs.
 // Roofline: MFMA (2*9*Cin*Cout algorithmic flop per OUTPUT pixel; executed: 2*4*Cin*Cout).
 #include "conv_mfma.hpp"
+#include "persist.hpp"
 
 namespace ire {
 
@@ -51,7 +52,7 @@ __device__ __forceinline__ void up_glds16(const void* gsrc, unsigned lds_dst_uni
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
 }
 
-struct UpItem { int img, ty, tx, nb; };
+using UpItem = PersistItem;
 struct UpRegs { uint4 v[UP_IN_ITERS]; };
 
 __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
@@ -62,34 +63,14 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
     const int r = lane & 31, h = lane >> 5;
     const int c8_fixed = tid & 3;
 
-    // ---- persistent work assignment, XCD-aware (as conv_rb.hip) --------------------------------------------------
-    const int tiles_per_img = a.tiles_x * a.tiles_y;
-    const int items = tiles_per_img * a.nimg * a.nblocks;
-    const int G = gridDim.x;
-    const int X = G < 8 ? G : 8;
-    const int xcd = blockIdx.x % X, jx = blockIdx.x / X;
-    const int nwx = (G - xcd + X - 1) / X;
-    const int lo = (int)((long long)items * xcd / X), hi = (int)((long long)items * (xcd + 1) / X);
-    const int my_items = (lo + jx < hi) ? (hi - lo - jx + nwx - 1) / nwx : 0;
-    const int nkc = a.nkc;                               // 32-channel stages per item (>= 2)
-    const int S = my_items * nkc;
+    // ---- persistent work assignment (persist.hpp) ---------------------------------------------------------------
+    PersistCursor cursor(a.tiles_x, a.tiles_y, a.nimg, a.nblocks, a.nkc);
+    const int my_items = cursor.my_items;
+    const int nkc = a.nkc;                               // 32-channel stages per item (>= 2, even)
+    const int S = cursor.S;
     if (S == 0) return;
-
-    struct StageInfo { UpItem it; int kc; };
-    auto decode = [&](int s) -> StageInfo {
-        const int k = s / nkc;
-        const int L = lo + jx + k * nwx;
-        StageInfo si;
-        si.it.nb = L % a.nblocks;
-        const int t = L / a.nblocks;
-        si.it.img = t / tiles_per_img;
-        const int tile = t - si.it.img * tiles_per_img;
-        si.it.ty = tile / a.tiles_x;
-        si.it.tx = tile - si.it.ty * a.tiles_x;
-        si.kc = s - k * nkc;
-        return si;
-    };
-    StageInfo sq0 = decode(0), sq1 = decode(min(1, S - 1)), sq2 = decode(min(2, S - 1));
+    using StageInfo = PersistStage;
+    StageInfo sq0 = cursor.cur, sq1 = cursor.next(), sq2 = cursor.next();
 
     const int Cin = a.cin0;
     const int cin_shift = 31 - __builtin_clz(Cin);
@@ -263,7 +244,7 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (LAST) epilogue(sq0.it);
         __syncthreads();
-        sq0 = sq1; sq1 = sq2; sq2 = decode(min(s + 3, S - 1));
+        sq0 = sq1; sq1 = sq2; sq2 = cursor.next();
     };
 
     // ---- prologue: stage 0 -> LDS buffer 0, stage 1 -> registers -----------------------------------------------------------

@@ -15,6 +15,7 @@
 // activated (gn_apply_silu): plain copy while staging.  Epilogue: the 128-channel tile leaves in 4 passes of 32
 // channels through the current stage buffer (bias, residual, GroupNorm partials, full-line stores).
 #include "conv_mfma.hpp"
+#include "persist.hpp"
 
 #include <cstdlib>
 #include <type_traits>
@@ -60,7 +61,7 @@ __device__ __forceinline__ float w4_swap32_add(float v) {
     return x + y;
 }
 
-struct W4Item { int img, ty, tx, nb, tile; };
+using W4Item = PersistItem;
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 template <int N> struct W4Regs { u32x4_t v[N]; unsigned ok; };   // native 128-bit tuples: one register quad per load
 
@@ -113,34 +114,15 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
     const int r = lane & 31, h = lane >> 5;
     const int c8_fixed = tid & 1;   // 2 chunks per pixel per stage
 
-    // ---- persistent work assignment (as conv_rb.hip) ------------------------------------------------------
+    // ---- persistent work assignment (persist.hpp) ---------------------------------------------------------------
     const int tiles_per_img = a.tiles_x * a.tiles_y;
-    const int items = tiles_per_img * a.nimg * a.nblocks;
-    const int G = gridDim.x;
-    const int X = G < 8 ? G : 8;
-    const int xcd = blockIdx.x % X, jx = blockIdx.x / X;
-    const int nwx = (G - xcd + X - 1) / X;
-    const int lo = (int)((long long)items * xcd / X), hi = (int)((long long)items * (xcd + 1) / X);
-    const int my_items = (lo + jx < hi) ? (hi - lo - jx + nwx - 1) / nwx : 0;
+    PersistCursor cursor(a.tiles_x, a.tiles_y, a.nimg, a.nblocks, a.nkc);
+    const int my_items = cursor.my_items;
     const int nkc = a.nkc;                         // 16-channel stages per item
-    const int S = my_items * nkc;
+    const int S = cursor.S;
     if (S == 0) return;
-
-    struct StageInfo { W4Item it; int kc; };
-    auto decode = [&](int s) -> StageInfo {
-        const int k = s / nkc;
-        const int L = lo + jx + k * nwx;
-        StageInfo si;
-        si.it.nb = L % a.nblocks;
-        const int t = L / a.nblocks;
-        si.it.img = t / tiles_per_img;
-        si.it.tile = t - si.it.img * tiles_per_img;
-        si.it.ty = si.it.tile / a.tiles_x;
-        si.it.tx = si.it.tile - si.it.ty * a.tiles_x;
-        si.kc = s - k * nkc;
-        return si;
-    };
-    StageInfo sq0 = decode(0), sq1 = decode(min(1, S - 1)), sq2 = decode(min(2, S - 1));
+    using StageInfo = PersistStage;
+    StageInfo sq0 = cursor.cur, sq1 = cursor.next(), sq2 = cursor.next();
 
     const int Cin = a.cin0;
     const int cin_shift = 31 - __builtin_clz(Cin);
@@ -521,7 +503,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
         stamp(4);
         __syncthreads();          // stage barrier: buf[nxt] complete, buf[cur] free
         stamp(5);
-        sq0 = sq1; sq1 = sq2; sq2 = decode(min(s + 3, S - 1));
+        sq0 = sq1; sq1 = sq2; sq2 = cursor.next();
         widx = widx == 2 ? 0 : widx + 1;
         par ^= 1;
     };
