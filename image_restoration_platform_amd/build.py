@@ -22,6 +22,7 @@ SOURCES = [
     ("conv_w4.hip", (["-DIRE_W4_STAMPS"] if os.environ.get("IRE_RB_ABLATE") else []) +
      (["-DIRE_W4_TICKS"] if os.environ.get("IRE_RB_ABLATE") == "2" else [])),
     ("conv_up.hip", []),
+    ("conv_down.hip", []),
     ("gn.hip", []),
     ("fusion.hip", []),
     ("preprocess.hip", []),

@@ -91,6 +91,7 @@ Engine::Engine(const ire_config& cfg) {
     if (const char* v = std::getenv("IRE_UP_RB_MINC")) up_rb_min_c_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_UP_SUBPIX")) up_subpixel_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_HEAD_RB")) head_rb_ = std::atoi(v);
+    if (const char* v = std::getenv("IRE_DOWN_RB")) down_rb_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_RB_STAMPS")) {   // diagnostic: "<cout>[r]" = stamp the first such ResBlock conv
         stamps_cout_ = std::atoi(v);
         stamps_resid_ = std::strchr(v, 'r') != nullptr;
@@ -233,6 +234,31 @@ ConvW Engine::make_conv(ConvKind kind, const std::string& wname, const std::stri
         c.d_wp = (unsigned short*)dalloc(arrp.size() * 2);
         net_.allocs.push_back(c.d_wp);
         IRE_HIP(hipMemcpy(c.d_wp, arrp.data(), arrp.size() * 2, hipMemcpyHostToDevice));
+    }
+    if (kind == CONV_DOWN && cin % 32 == 0 && cout % 64 == 0) {
+        // conv_down.hip: the stride-2 conv as a unit-stride conv over the four pixel phases P_ab[Y][X] = in[2Y+a][2X+b]:
+        // phase (a, b) carries the taps ky in (a ? {0, 2} : {1}) x kx in (b ? {0, 2} : {1}), in that order
+        const int nbd = cout / 64, nkd = cin / 32;
+        std::vector<unsigned short> arrd((size_t)nbd * nkd * 9 * 4 * 64 * 8, 0);
+        size_t pos = 0;
+        for (int nb = 0; nb < nbd; ++nb)
+            for (int kc = 0; kc < nkd; ++kc)
+                for (int ph = 0; ph < 4; ++ph) {
+                    const int pa = ph >> 1, pb = ph & 1, nty = pa ? 2 : 1, ntx = pb ? 2 : 1;
+                    for (int t = 0; t < nty * ntx; ++t) {
+                        const int ty = t / ntx, tx = t % ntx;
+                        const int ky = pa ? (ty ? 2 : 0) : 1, kx = pb ? (tx ? 2 : 0) : 1;
+                        for (int c8 = 0; c8 < 4; ++c8)
+                            for (int n = 0; n < 64; ++n)
+                                for (int e = 0; e < 8; ++e) {
+                                    const int co = nb * 64 + (n & 32) + perm(n & 31), ci = kc * 32 + c8 * 8 + e;
+                                    arrd[pos++] = f32_to_bf16(W[((size_t)co * cin + ci) * 9 + ky * 3 + kx]);
+                                }
+                    }
+                }
+        c.d_wd = (unsigned short*)dalloc(arrd.size() * 2);
+        net_.allocs.push_back(c.d_wd);
+        IRE_HIP(hipMemcpy(c.d_wd, arrd.data(), arrd.size() * 2, hipMemcpyHostToDevice));
     }
     if (kind == CONV_UP && cin % 64 == 0 && cout % 32 == 0) {
         // conv_up.hip: nearest x2 -> 3x3 == four 2x2 convolutions on the low-res grid, one per output parity (pa, pb); the taps that
@@ -690,7 +716,8 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     const bool up_rb = (cw.kind == CONV_UP) && rb_tile_h_ == kRbTileH && cw.cout >= up_rb_min_c_;
     const bool up_sub = up_rb && up_subpixel_ && cw.d_wu != nullptr;       // sub-pixel form: tiles and halo rows on the LOW-res grid
     const bool head_rb = cw.kind == CONV_HEAD && rb_tile_h_ == kRbTileH && head_rb_ && cw.d_wp != nullptr;    // the head on the pipelined kernel
-    const int th = (rb || up_rb || head_rb) ? rb_tile_h_ : conv_tile_h(cw.kind);
+    const bool down_rb = cw.kind == CONV_DOWN && rb_tile_h_ == kRbTileH && down_rb_ && cw.d_wd != nullptr;    // stride-2 convs by pixel phase
+    const int th = (rb || up_rb || head_rb || down_rb) ? rb_tile_h_ : conv_tile_h(cw.kind);
     a.tiles_y = ceil_div(Hout, th);
     if (up_sub) {
         a.tiles_x = ceil_div(Win, 32); a.tiles_y = ceil_div(Hin, 16);
@@ -735,6 +762,7 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
         }
         conv_w4_launch(cw.kind == CONV_RB2, a, R.stream);
     } else if (head_rb) { a.w = cw.d_wp; conv_head_launch(a, R.stream); }
+    else if (down_rb) { a.w = cw.d_wd; a.nkc = cw.cin / 32; a.nblocks = cw.cout / 64; conv_down_launch(a, R.stream); }
     else if (up_sub) { a.w = cw.d_wu; a.nkc = cw.cin / 32; a.nblocks = cw.cout / 32; conv_up_subpixel_launch(a, R.stream); }
     else if (up_rb) { if (cw.d_wp) a.w = cw.d_wp; conv_up_launch(a, R.stream); }
     else if (rb && rb_tile_h_ == kRbTileH) { if (cw.d_wp) a.w = cw.d_wp; conv_rb_launch(cw.kind == CONV_RB2, /*fused_act=*/a.ab != nullptr, a, R.stream); }
