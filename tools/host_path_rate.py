@@ -26,3 +26,15 @@ for j in jobs:
     eng.poll(j)
 dt = time.perf_counter() - t0
 print(f"ire_submit/ire_poll (64 single-image jobs, coalesced): {64 / dt:.1f} img/s")
+
+# the Node seams (N-API shim -> ire_submit / ire_poll): in-flight single-image restoreImage calls, raw codec
+import json, shutil, subprocess
+from image_restoration_platform_amd import weights
+if shutil.which("node"):
+    nd = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "image_restoration_platform_amd", "node", "rate_adapters.js")
+    eng.close()
+    for inflight in (3, 5, 8):
+        r = subprocess.run(["node", nd, weights.ensure_default(0), str(S), str(inflight), "64"], capture_output=True, text=True, timeout=600)
+        j = json.loads(r.stdout.strip().splitlines()[-1])
+        print(f"Node restoreImage, {inflight} in flight @{S}^2 (copy + base64-free raw codec): {j.get('imagesPerSec', 0):.1f} img/s, "
+              f"{j.get('engineBatches')} engine batches for {j.get('total')} jobs")
