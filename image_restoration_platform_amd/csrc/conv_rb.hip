@@ -30,12 +30,13 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
-constexpr int RB_THREADS = 512;
-constexpr int RB_TH = 16, RB_TW = 32;
+constexpr int RB_TH = kRbTileH, RB_TW = 32;          // 16 (8 waves x 2 rows); IRE_RB_TH=8: 4 waves x 2 rows
+constexpr int RB_WAVES = RB_TH / 2;
+constexpr int RB_THREADS = RB_WAVES * 64;
 constexpr int RB_IH = RB_TH + 2, RB_IW = RB_TW + 2;
 constexpr int RB_IN_CHUNKS = RB_IH * RB_IW * 4;                                // 2448 x 16 B
-constexpr int RB_IN_BYTES = 5 * RB_THREADS * 16;                               // 40960: padded so all 5x512 chunk slots exist
 constexpr int RB_IN_ITERS = (RB_IN_CHUNKS + RB_THREADS - 1) / RB_THREADS;       // 5
+constexpr int RB_IN_BYTES = RB_IN_ITERS * RB_THREADS * 16;                     // 40960: padded so all 5x512 chunk slots exist
 constexpr int RB_NSTEPS = 18;
 
 __device__ __forceinline__ unsigned rb_pack(float a, float b) {
@@ -100,7 +101,7 @@ struct RbCfg {
     static constexpr int BUF_STRIDE = WRES ? RB_IN_BYTES : RB_IN_BYTES + W_BYTES;
     static constexpr int W_OFF0 = WRES ? 2 * RB_IN_BYTES : RB_IN_BYTES;
     static constexpr int MAIN_BYTES = WRES ? 2 * RB_IN_BYTES + W_BYTES : 2 * (RB_IN_BYTES + W_BYTES);
-    static constexpr int RED_HALF = 8 * (NT / 8) * 4 * 4;     // [8 waves][NT/8 chunks][sA,qA,sB,qB]
+    static constexpr int RED_HALF = RB_WAVES * (NT / 8) * 4 * 4;     // [waves][NT/8 chunks][sA,qA,sB,qB]
     static constexpr int RED_BYTES = 2 * RED_HALF;             // two copies, alternating per item (DIRECT: no barrier before the write)
     static constexpr int COEF_BYTES = 2 * 256;              // two stages x 32 channels x (A,B) floats
     static constexpr int BIAS_BYTES = 256 * 4;              // the layer's whole bias vector (cout <= 256)
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
             float s = 0.f, q = 0.f;
             const int cpg = Gs >> 3;                       // 16-B chunks per group (0 when Gs == 4)
 #pragma unroll
-            for (int w = 0; w < 8; ++w) {
+            for (int w = 0; w < RB_WAVES; ++w) {
                 if (NT == 32) {                            // cout = 32 => groups of 4: a chunk holds two groups (cc, half)
                     const float* d = red + (w * NCC + (tid >> 1)) * 4 + 2 * (tid & 1);
                     s += d[0]; q += d[1];
@@ -568,9 +569,11 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         stamp(s, 1);
-        tw[2] = transform_word(word_of(Rn.v[4], 2), 2, cA, cB);   // pieces 18, 19: the (partial) fifth chunk
-        tw[3] = transform_word(word_of(Rn.v[4], 3), 3, cA, cB);
-        store_words(4, Rn, tw, in_nxt);
+#pragma unroll
+        for (int pc = RB_NSTEPS; pc < RB_IN_ITERS * 4; ++pc) {         // pieces 18, 19 (and 20..23 with 6 chunks per thread)
+            tw[pc & 3] = transform_word(word_of(Rn.v[pc >> 2], pc & 3), pc & 3, cA, cB);
+            if ((pc & 3) == 3) store_words(pc >> 2, Rn, tw, in_nxt);
+        }
         // The s+2 prefetch has had a whole stage to land: retire it NOW (it is the oldest thing in this wave's
         // in-order VMEM queue), so that no later wait -- in particular the next stage's first use of these
         // registers, which on the epilogue path comes after 8 output stores -- has to drain anything newer.
@@ -642,7 +645,9 @@ void launch_rb(const ConvArgs& a, hipStream_t stream) {
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int grid = items < cus ? items : cus;
+    // one workgroup per CU; with 8-row tiles (256 threads) two independent workgroups per CU where their LDS fits
+    const int per_cu = (RB_TH == 8 && RbCfg<NT, RESID, WRES, FUSED_ACT>::LDS_BYTES <= 80 * 1024) ? 2 : 1;
+    const int grid = items < cus * per_cu ? items : cus * per_cu;
     hipLaunchKernelGGL((conv_rb_kernel<NT, RESID, WRES, FUSED_ACT, DBG, UPS, HEAD>), dim3(grid), dim3(RB_THREADS), 0, stream, a);
     IRE_HIP(hipGetLastError());
 }

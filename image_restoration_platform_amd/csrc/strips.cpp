@@ -126,10 +126,8 @@ void StripSession::run_op(int k, hipStream_t s, ire_strip_xchg* info) {
     }
     if (op.stats_out && info) {
         // the slice of the partials array this session's strips just wrote (whole tiles rows: contiguous)
-        const bool rbk = op.cw->kind == CONV_RB1 || op.cw->kind == CONV_RB2 || (op.cw->kind == CONV_DOWN && E.down_rb_ && op.cw->d_wd);
-        const int th = rbk ? E.rb_tile_h_ : conv_tile_h(op.cw->kind);
-        const int tiles_x = ceil_div(W_ >> op.lout, 32);
-        const size_t per_strip = (size_t)((hr_ >> op.lout) / th) * tiles_x * 16 * 4;
+        // the partials the op wrote: run_.stat_parts tiles per image (exec_conv), an equal slice of them per strip
+        const size_t per_strip = (size_t)run_.stat_parts / total_ * 16 * 4;
         info->stats_offset_bytes = (long long)(per_strip * first_);
         info->stats_local_bytes = (long long)(per_strip * nlocal_);
         info->stats_total_bytes = (long long)(per_strip * total_);
