@@ -209,16 +209,26 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
         }
         return v;
     };
-    auto put_coeffs = [&](int slot, const float4& v) {
-        if constexpr (FUSED_ACT) { if (tid < 16) reinterpret_cast<float4*>(coef_lds + slot * 64)[tid] = v; }
+    // LDS slot = A[32 channels] then B[32 channels] (gn_finalize stores (A, B) pairs): a thread's 8 A's and 8 B's then arrive as
+    // two register quads each, so the (A_2d, A_2d+1) / (B_2d, B_2d+1) operands of the packed fma are adjacent registers as loaded
+    // (from (A, B, A, B) quads hipcc needed three v_mov per word to pair them up: 60 per stage)
+    auto put_coeffs = [&](int slot, const float4& v) {      // lane l < 16 holds (A, B) of channels 2l, 2l+1
+        if constexpr (FUSED_ACT) {
+            if (tid < 16) {
+                reinterpret_cast<float2*>(coef_lds + slot * 64)[tid] = make_float2(v.x, v.z);
+                reinterpret_cast<float2*>(coef_lds + slot * 64 + 32)[tid] = make_float2(v.y, v.w);
+            }
+        }
     };
     auto load_coeffs = [&](int slot, float (&cA)[8], float (&cB)[8]) {
         if constexpr (!FUSED_ACT) return;
-        const float4* ab = reinterpret_cast<const float4*>(coef_lds + slot * 64 + c8_fixed * 16);
+        const float4* pa = reinterpret_cast<const float4*>(coef_lds + slot * 64 + c8_fixed * 8);
+        const float4* pb = reinterpret_cast<const float4*>(coef_lds + slot * 64 + 32 + c8_fixed * 8);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float4 v = ab[e];
-            cA[2 * e] = v.x; cB[2 * e] = v.y; cA[2 * e + 1] = v.z; cB[2 * e + 1] = v.w;
+        for (int e = 0; e < 2; ++e) {
+            const float4 va = pa[e], vb = pb[e];
+            cA[4 * e] = va.x; cA[4 * e + 1] = va.y; cA[4 * e + 2] = va.z; cA[4 * e + 3] = va.w;
+            cB[4 * e] = vb.x; cB[4 * e + 1] = vb.y; cB[4 * e + 2] = vb.z; cB[4 * e + 3] = vb.w;
         }
     };
     // The s+1 transform is cut into 20 word-sized pieces (5 chunks x 4 words of 2 channels) so that one
@@ -545,7 +555,8 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m) asm volatile("" :: "v"(afr[st & 1][m]));
             }
-            {   // piece st of the s+1 transform (chunk st>>2, word st&3)
+            {   // piece st of the s+1 transform (chunk st>>2, word st&3); two pieces per even k-step (interleaved dependency chains) measured
+                // no better (profiles/r02_experiments.md)
                 tw[st & 3] = transform_word(word_of(Rn.v[st >> 2], st & 3), st & 3, cA, cB);
                 if ((st & 3) == 3) store_words(st >> 2, Rn, tw, in_nxt);
             }
