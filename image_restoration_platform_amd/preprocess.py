@@ -56,7 +56,10 @@ def preprocess_image(engine, data, max_dim=MAX_DIMENSION, quality=JPEG_QUALITY):
         operations.append(f"resize_{_js_round(width * scale)}x{_js_round(height * scale)}")      # the box, as :54 logs it
     buf = io.BytesIO()
     # 4:4:4 = subsampling 0; mozjpeg's trellis/progressive tuning has no Pillow switch: optimize=True is the nearest setting
-    Image.fromarray(out).save(buf, format="JPEG", quality=quality, subsampling=0, optimize=True)
+    # .withMetadata({icc: 'sRGB'}) (:65-68): the output carries an sRGB ICC profile (the standard one PIL / LittleCMS builds)
+    from PIL import ImageCms
+    icc = ImageCms.ImageCmsProfile(ImageCms.createProfile("sRGB")).tobytes()
+    Image.fromarray(out).save(buf, format="JPEG", quality=quality, subsampling=0, optimize=True, icc_profile=icc)
     operations += [f"compress_jpeg_q{quality}", "attach_sRGB_icc"]
     return {
         "buffer": buf.getvalue(),

@@ -6,6 +6,9 @@ with the endpoints its docs sketch (image-restoration-platform.md:1076-1127):
                   ?preprocess=1 first runs the upload through the preprocess step of imagePreprocess.js:24-91
                   (auto-orient + fit inside 2048 on the GPU, JPEG q85 4:4:4) as the Node middleware does before queueing
   POST /fuse      JSON {"images": [base64, ...2..3], "prompt": "..."}                 -> {base64Image, metadata}
+  POST /restore_batch  JSON {"images": [base64, ...], "prompt": "..."}                -> [RestoratorService envelope, ...] in order
+                  restoreBatch (restorator.js:181-236) through the PyTorch-ROCm extension (torch_host.TorchEngine): images of
+                  one shape are stacked into ONE uint8 tensor, classified and restored as one engine batch on the GPU
   GET  /health/ready                                                                 -> service + engine health
 The engine is created on first use; without a gfx950 device every compute endpoint answers 503 with the
 engine's "service unavailable" message (there is no CPU fallback).
@@ -22,7 +25,16 @@ from ..restorator import EngineRestorer, RestoratorService
 
 app = FastAPI(title="image-restoration engine (MI355X)")
 _lock = threading.Lock()
-_state = {"engine": None, "service": None, "error": None}
+_state = {"engine": None, "service": None, "error": None, "torch_engine": None}
+
+
+def get_torch_engine():
+    """The tensor host (csrc/torch_ext.cpp): created on first use, beside the ctypes engine the single-image endpoints use."""
+    with _lock:
+        if _state["torch_engine"] is None:
+            from ..torch_host import TorchEngine
+            _state["torch_engine"] = TorchEngine(device_index=0, max_batch=8)
+        return _state["torch_engine"]
 
 
 def get_service():
@@ -89,6 +101,72 @@ async def restore(request: Request, prompt: str = None, preprocess: int = 0):
     if operations is not None:
         result["metadata"]["preprocessOperations"] = operations        # req.file.preprocessOperations, imagePreprocess.js:78
     return result
+
+
+@app.post("/restore_batch")
+async def restore_batch(request: Request):
+    """restoreBatch (restorator.js:181-236): same envelope per image, same order; the images go to the GPU as tensors."""
+    import time
+    import numpy as np
+    import torch
+    from ..prompt_enhancer import KEYS, PromptEnhancerService
+    from ..restorator import decode_image, encode_png_base64, pad_to_multiple
+    try:
+        payload = await request.json()
+        bufs = [base64.b64decode(b) for b in payload["images"]]
+        if not bufs:
+            raise ValueError("empty")
+    except Exception:  # noqa: BLE001
+        return _problem(400, "Bad Request", "invalid request: expected JSON {images: [base64, ...]}")
+    try:
+        te = get_torch_engine()
+    except Exception as e:  # noqa: BLE001
+        return _problem(503, "Service Unavailable", str(e))
+    enhancer = PromptEnhancerService(None)
+    results = [None] * len(bufs)
+    decoded, groups = {}, {}
+    for i, b in enumerate(bufs):
+        try:
+            rgb, fmt = decode_image(b)
+            padded, hw = pad_to_multiple(rgb)
+            decoded[i] = (padded, hw, fmt, rgb)
+            groups.setdefault(padded.shape, []).append(i)
+        except Exception as e:  # noqa: BLE001 -- the reference's envelope for a failed image (restorator.js:141-167)
+            results[i] = {"success": False, "error": {"message": str(e), "code": "RESTORATION_FAILED", "type": "INVALID_INPUT"},
+                          "timings": {"total_ms": 0}, "metadata": {"processingTime": 0, "failureStage": "CLASSIFICATION"}}
+    for shape, idxs in groups.items():
+        for c0 in range(0, len(idxs), 8):
+            chunk = idxs[c0:c0 + 8]
+            t0 = time.time()
+            try:
+                x = torch.from_numpy(np.stack([decoded[i][0] for i in chunk])).cuda()
+                jp = torch.tensor([1 if decoded[i][2] == "jpeg" else 0 for i in chunk], dtype=torch.uint8, device="cuda")
+                # condition on each image's own scores (unpadded pixels), as analyze() reports them
+                same = all(decoded[i][0].shape == decoded[i][3].shape for i in chunk)
+                if same:
+                    scores, _ = te.classify(x, jp)
+                else:
+                    scores = torch.cat([te.classify(torch.from_numpy(decoded[i][3][None]).cuda(), jp[k:k + 1])[0] for k, i in enumerate(chunk)])
+                t1 = time.time()
+                out = te.restore(x, scores, None).cpu().numpy()
+                sc = scores.cpu().numpy()
+                t2 = time.time()
+            except EngineError as e:
+                for i in chunk:
+                    results[i] = {"success": False, "error": {"message": e.message, "code": e.code, "type": RestoratorService._classify_error(e)},
+                                  "timings": {}, "metadata": {"processingTime": 0, "failureStage": "AI_RESTORATION"}}
+                continue
+            for k, i in enumerate(chunk):
+                h, w = decoded[i][1]
+                degradation = {key: float(sc[k, j]) for j, key in enumerate(KEYS)}
+                results[i] = {
+                    "success": True, "restoredImage": encode_png_base64(np.ascontiguousarray(out[k, :h, :w])),
+                    "degradationAnalysis": degradation,
+                    "enhancedPrompt": enhancer.enhance(degradation=degradation, user_prompt=payload.get("prompt"), options={"batchIndex": i, "batchSize": len(bufs)}),
+                    "timings": {"classify_ms": int(1e3 * (t1 - t0)), "prompt_ms": 0, "restore_ms": int(1e3 * (t2 - t1)), "total_ms": int(1e3 * (t2 - t0))},
+                    "metadata": {"providerRequestId": f"ire-batch-{i}", "estimatedCostUsd": 0, "billedTokens": None, "processingTime": int(1e3 * (t2 - t0)),
+                                 "classificationIssues": [{"type": key, "confidence": v} for key, v in degradation.items() if v > 0.3]}}
+    return results
 
 
 @app.post("/fuse")

@@ -48,4 +48,13 @@ def test_restore_and_fuse_endpoints():
     r = c.post("/fuse", json={"images": [base64.b64encode(_jpeg(v)).decode() for v in views]})
     assert r.status_code == 200 and r.json()["metadata"]["estimatedCostUsd"] == 0
     assert c.post("/fuse", json={"images": ["AAAA"]}).status_code == 400
-    assert c.get("/health/ready").json()["ok"] is True
+    rd = c.get("/health/ready").json()
+    assert rd["ok"] is True and rd["status"] == "ok" and rd["dependencies"]["engine"]["status"] == "ok" and rd["dependencies"]["engine"]["images"] >= 2
+    # restoreBatch through the PyTorch-ROCm extension: mixed shapes, one undecodable image; same pixels as the single-image endpoint
+    imgs = [synth.image(2, 96, 120), synth.image(5, 64, 64), synth.image(6, 96, 120)]
+    r = c.post("/restore_batch", json={"images": [base64.b64encode(_jpeg(i)).decode() for i in imgs] + [base64.b64encode(b"junk").decode()], "prompt": "fix"})
+    assert r.status_code == 200, r.text
+    res = r.json()
+    assert [x["success"] for x in res] == [True, True, True, False] and res[3]["error"]["type"] == "INVALID_INPUT"
+    assert res[0]["restoredImage"] == j["restoredImage"] and res[0]["degradationAnalysis"] == j["degradationAnalysis"]
+    assert res[1]["timings"].keys() == {"classify_ms", "prompt_ms", "restore_ms", "total_ms"}
