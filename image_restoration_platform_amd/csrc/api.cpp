@@ -161,10 +161,19 @@ static void batcher_loop(ire_engine* E) {
             if (prev.busy && E->queue.empty() && !E->stop) { lk.unlock(); slot_finish(E, prev); lk.lock(); }
             E->qcv.wait(lk, [&] { return E->stop || !E->queue.empty(); });
             if (E->stop && E->queue.empty()) break;
-            // small coalescing window: more submissions of the same shape usually follow at once
-            if ((int)E->queue.size() < E->eng->max_batch() && !prev.busy) {
-                E->qcv.wait_for(lk, std::chrono::microseconds(200),
-                                [&] { return E->stop || (int)E->queue.size() >= E->eng->max_batch(); });
+            // coalescing: more submissions of the same shape usually follow at once.  Idle GPU: a 200 us window.  GPU busy with the
+            // previous batch: its jobs come back (and are re-submitted by a closed-loop caller: 3 per restoreBatch, 5 per worker) only
+            // when it ends, so a batch launched now would be whatever trickled in -- keep gathering until this batch is as large as
+            // the one in flight, or that one has finished computing (then nothing is gained by waiting)
+            if ((int)E->queue.size() < E->eng->max_batch()) {
+                if (!prev.busy) {
+                    E->qcv.wait_for(lk, std::chrono::microseconds(200),
+                                    [&] { return E->stop || (int)E->queue.size() >= E->eng->max_batch(); });
+                } else {
+                    const int want = std::min(E->eng->max_batch(), (int)prev.jobs.size());
+                    while (!E->stop && (int)E->queue.size() < want && prev.status == IRE_OK && hipEventQuery(prev.ev_c1) == hipErrorNotReady)
+                        E->qcv.wait_for(lk, std::chrono::microseconds(50));
+                }
             }
             S.h = E->queue.front()->h; S.w = E->queue.front()->w;
             for (auto it = E->queue.begin(); it != E->queue.end() && (int)S.jobs.size() < E->eng->max_batch();) {

@@ -108,7 +108,9 @@ def test_preprocess_image_round_trip(engine):
     assert np.array_equal(rec["pixels"], opp.preprocess_pixels(a, 6, 256)[0])
     out = Image.open(io.BytesIO(rec["buffer"]))
     assert out.format == "JPEG" and out.size == (rec["processed_metadata"]["width"], rec["processed_metadata"]["height"])
-    assert out.info.get("icc_profile") and b"sRGB" in out.info["icc_profile"]       # 'attach_sRGB_icc' is what it says (imagePreprocess.js:65-68)
+    from PIL import ImageCms
+    prof = ImageCms.ImageCmsProfile(io.BytesIO(out.info["icc_profile"]))              # 'attach_sRGB_icc' is what it says (imagePreprocess.js:65-68)
+    assert "sRGB" in ImageCms.getProfileDescription(prof) and prof.profile.xcolor_space.strip() == "RGB"
     with pytest.raises(PreprocessError) as e:
         preprocess_image(engine, b"")
     assert e.value.status == 400
