@@ -23,6 +23,7 @@ SOURCES = [
      (["-DIRE_W4_TICKS"] if os.environ.get("IRE_RB_ABLATE") == "2" else [])),
     ("conv_up.hip", []),
     ("conv_down.hip", []),
+    ("conv_f8.hip", []),
     ("gn.hip", []),
     ("fusion.hip", []),
     ("preprocess.hip", []),

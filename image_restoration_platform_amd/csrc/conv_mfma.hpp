@@ -62,6 +62,9 @@ void conv_rb_launch(bool resid, bool fused_act, const ConvArgs& a, hipStream_t s
 // One-wave-per-SIMD variant for C >= 128 ResBlock convs on a pre-activated input (conv_w4.hip):
 // a.nkc = Cin/16, a.nblocks = cout/128, a.w = slabs [nblock][kc16][tap*2 + c8][128][8], 16x32 tiles.
 void conv_w4_launch(bool resid, const ConvArgs& a, hipStream_t stream);
+// IRE_PRECISION_FP8: C >= 128 ResBlock convs on the block-scaled fp8 MFMA, K = 64 per instruction (conv_f8.hip).
+// a.nkc = Cin/32, a.nblocks = cout/128, a.w = e4m3 slabs [nblock][kc32][tap][half][128][16], a.bias = bias / oscale, a.oscale.
+void conv_f8_launch(bool resid, const ConvArgs& a, hipStream_t stream);
 // CONV_DOWN on the pipelined schedule (conv_down.hip): the stride-2 conv as a unit-stride conv over the four pixel phases.
 // a.Hin/Win = full-res source, a.Hout/Wout = half; a.nkc = Cin/32, a.nblocks = cout/64, tiles of 16x32 OUTPUT pixels.
 void conv_down_launch(const ConvArgs& a, hipStream_t stream);

@@ -92,6 +92,7 @@ Engine::Engine(const ire_config& cfg) {
     if (const char* v = std::getenv("IRE_UP_SUBPIX")) up_subpixel_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_HEAD_RB")) head_rb_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_DOWN_RB")) down_rb_ = std::atoi(v);
+    if (const char* v = std::getenv("IRE_FP8_MX")) fp8_mx_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_RB_STAMPS")) {   // diagnostic: "<cout>[r]" = stamp the first such ResBlock conv
         stamps_cout_ = std::atoi(v);
         stamps_resid_ = std::strchr(v, 'r') != nullptr;
@@ -327,6 +328,23 @@ ConvW Engine::make_conv(ConvKind kind, const std::string& wname, const std::stri
                                 arr8[((((size_t)nb * nk4 + kc) * 18 + kk) * 128 + n) * 8 + e] = f32_to_e4m3(W[((size_t)co * cin + ci) * 9 + tap] / sw[co]);
                             }
                     }
+            // the K = 64 form (conv_f8.hip): 32-channel stages, [tap][16-channel half][128 rows][16 bytes]
+            if (cin % 32 == 0) {
+                const int nk8 = cin / 32;
+                std::vector<unsigned char> arrx((size_t)nb4 * nk8 * 9 * 2 * 128 * 16, 0);
+                for (int nb = 0; nb < nb4; ++nb)
+                    for (int kc = 0; kc < nk8; ++kc)
+                        for (int tap = 0; tap < 9; ++tap)
+                            for (int hf = 0; hf < 2; ++hf)
+                                for (int n = 0; n < 128; ++n)
+                                    for (int e = 0; e < 16; ++e) {
+                                        const int co = nb * 128 + perm(n), ci = kc * 32 + hf * 16 + e;
+                                        arrx[(((((size_t)nb * nk8 + kc) * 9 + tap) * 2 + hf) * 128 + n) * 16 + e] = f32_to_e4m3(W[((size_t)co * cin + ci) * 9 + tap] / sw[co]);
+                                    }
+                c.d_w8x = (unsigned char*)dalloc(arrx.size());
+                net_.allocs.push_back(c.d_w8x);
+                IRE_HIP(hipMemcpy(c.d_w8x, arrx.data(), arrx.size(), hipMemcpyHostToDevice));
+            }
             c.d_w8 = (unsigned char*)dalloc(arr8.size());
             c.d_oscale = (float*)dalloc(cout * 4);
             c.d_bias8 = (float*)dalloc(cout * 4);
@@ -755,7 +773,11 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     prof_begin(fam, R.stream, flops, bytes);
     // conv_w4: pre-activated input (ab == nullptr) or, from w4_fused_min_c_ up, activation fused into its staging (8-wave form)
     const bool w4 = rb && rb_tile_h_ == kRbTileH && use_w4_ && cw.d_w4 != nullptr && (a.ab == nullptr || cw.cout >= w4_fused_min_c_);
-    if (w4) {
+    if (w4 && fp8_mx_ && cw.d_w8x != nullptr && a.ab != nullptr) {   // IRE_PRECISION_FP8: the 2x-rate block-scaled fp8 MFMA
+        a.fp8 = 1; a.w = reinterpret_cast<const unsigned short*>(cw.d_w8x); a.bias = cw.d_bias8; a.oscale = cw.d_oscale;
+        a.nkc = cw.cin / 32; a.nblocks = cw.cout / 128;
+        conv_f8_launch(cw.kind == CONV_RB2, a, R.stream);
+    } else if (w4) {
         a.w = cw.d_w4; a.nkc = cw.cin / 16; a.nblocks = cw.cout / 128;
         if (cw.d_w8 != nullptr && a.ab != nullptr) {      // IRE_PRECISION_FP8: e4m3 operands for the C >= 128 ResBlock convs
             a.fp8 = 1; a.w = reinterpret_cast<const unsigned short*>(cw.d_w8); a.bias = cw.d_bias8; a.oscale = cw.d_oscale;

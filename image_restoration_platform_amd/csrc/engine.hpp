@@ -31,6 +31,7 @@ struct ConvW {
     unsigned short* d_w4 = nullptr;  // second arrangement for conv_w4.hip (C >= 128 ResBlock convs): 16-channel stages, 128-cout blocks
     unsigned short* d_wd = nullptr;  // CONV_DOWN by pixel phase (conv_down.hip): [nblock64][kc32][phase: 1+2+2+4 taps][tap*4 + c8][64][8]
     unsigned short* d_wu = nullptr;  // CONV_UP as a sub-pixel conv (conv_up.hip): [nblock32][kc32][parity][kk][32][8], taps pre-summed per parity
+    unsigned char* d_w8x = nullptr;  // IRE_PRECISION_FP8, K = 64 form (conv_f8.hip): [nblock128][kc32][tap][half][128][16] e4m3
     unsigned char* d_w8 = nullptr;   // IRE_PRECISION_FP8: the conv_w4 slabs as OCP e4m3, one scale per output channel
     float* d_oscale = nullptr;       // [cout] weight scale / activation scale (accumulator -> output)
     float* d_bias8 = nullptr;        // [cout] bias / oscale (the accumulators start at it)
@@ -195,6 +196,7 @@ private:
     int w4_fused_min_c_ = 128;      // IRE_W4_FUSED_MINC: ResBlock convs with fused activation and cout >= this run on conv_w4's fused variant
     int w4_waves_ = 8;            // IRE_W4_WAVES=4: the one-wave-per-SIMD form, pre-activated inputs only (fused activation needs the 8-wave form)
     int use_w4_ = 1;              // C >= 128 ResBlock convs on conv_w4.hip (IRE_W4=0: conv_rb.hip; IRE_W4_WAVES=4|8)
+    int fp8_mx_ = 1;              // fp8: the block-scaled K = 64 MFMA (conv_f8.hip); IRE_FP8_MX=0: the same-rate 32x32x16 fp8 form in conv_w4.hip
     int down_rb_ = 1;             // stride-2 `down` convs on conv_down.hip's pipelined phase kernel (IRE_DOWN_RB=0: the v1 kernel)
     int head_rb_ = 1;             // the 32 -> 3 head conv on conv_rb.hip's pipelined kernel (IRE_HEAD_RB=0: the v1 kernel)
     int up_subpixel_ = 1;         // `up` convs as sub-pixel convolutions on the low-res grid (IRE_UP_SUBPIX=0: nearest x2 + 3x3 on conv_rb.hip)
