@@ -24,6 +24,7 @@ struct ConvArgs {
     int kc_split;                // number of 32-channel K-chunks read from in0 (rest from in1)
     int nkc;                     // total K-chunks
     const unsigned short* w;     // weights pre-arranged [nblock][kchunk][kk][NT][8] bf16
+    const unsigned short* w1;    // conv_up.hip fused with `fuse`: skip weights [nblock32][ks][h][32][8] bf16, else null
     const float* bias;           // [cout]
     const float2* ab;            // [nimg][cin0] GroupNorm+FiLM coefficients (PRO_GN)
     const unsigned short* resid; // [nimg][Hout][Wout][cout] bf16 (CONV_RB2)

@@ -15,8 +15,19 @@
 // low-res rows 2w, 2w+1 and keeps 4 parities x 2 rows x 32 couts = 128 accumulators.  Per stage a tap's two pixel fragments
 // are read once and feed every parity whose window contains the tap: 36 + 32 fragment reads for 64 MFMAs.
 // Roofline: MFMA (2*9*Cin*Cout algorithmic flop per OUTPUT pixel; executed: 2*4*Cin*Cout).
+//
+// FUSED form (NKS > 0): RestoreNet-v0 follows every `up` with the 1x1 `fuse` over concat(up, skip) and nothing non-linear
+// sits between them, so   fuse(concat(up(x), skip)) = (Wf_up . Wup) * x_up  +  Wf_skip . skip  +  (Wf_up . b_up + b_f):
+// engine.cpp::make_up_fused composes the two weight tensors once per load (fp64, then the sub-pixel pre-sums, then bf16) and
+// this kernel adds the skip term in its epilogue: the accumulator tile of a (parity, row) is D[cout][pixel], the skip pixels
+// come straight from HBM in the MFMA B layout (lane = pixel, 8 channels = 16 B) and the 32 x C skip weights of the item's
+// cout block wait in LDS (LDS-DMA one stage ahead).  The `up` tensor is never written or read (2 x 2 B x C per output pixel
+// less traffic, one launch less per level), `fuse`'s 2*C*C flop per pixel over the up half are gone, and the epilogue also
+// writes the GroupNorm partials `fuse` used to write: one (sum, sumsq) per group per ITEM (32 x 64 output pixels).
 #include "conv_mfma.hpp"
 #include "persist.hpp"
+
+#include <type_traits>
 
 namespace ire {
 
@@ -39,7 +50,11 @@ constexpr int UP_W_CHUNKS = 4 * 16 * UP_NT;           // [parity][kk = tap4*4 + 
 constexpr int UP_W_BYTES = UP_W_CHUNKS * 16;
 constexpr int UP_W_ITERS = UP_W_CHUNKS / UP_THREADS;   // 4
 constexpr int UP_BUF = UP_IN_BYTES + UP_W_BYTES;
-constexpr int UP_LDS = 2 * UP_BUF + 256 * 4;
+constexpr int UP_BIAS_OFF = 2 * UP_BUF;                // 256 floats
+constexpr int UP_SKW_OFF = UP_BIAS_OFF + 256 * 4;      // fused form: skip weights of the item's cout block [ks][h][32 rows][8] bf16, <= 8 KB
+constexpr int UP_RED_OFF = UP_SKW_OFF + 8192;          // fused form: [8 waves][8 cout quads][2] floats
+constexpr int UP_LDS = UP_RED_OFF + 8 * 8 * 2 * 4;
+static_assert(UP_LDS <= 160 * 1024, "LDS");
 
 __device__ __forceinline__ unsigned up_pack(float a, float b) {
     f32x2_t f = {a, b};
@@ -52,9 +67,25 @@ __device__ __forceinline__ void up_glds16(const void* gsrc, unsigned lds_dst_uni
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
 }
 
+template <int N> __device__ __forceinline__ float up_ror_add(float v) {
+    const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false);
+    return v + __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ float up_swap16_add(float v) {
+    float x = v, y = v;
+    asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return x + y;
+}
+
+template <int I, int N, class F> __device__ __forceinline__ void up_static_for(F& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); up_static_for<I + 1, N>(f); }
+}
+
 using UpItem = PersistItem;
 struct UpRegs { uint4 v[UP_IN_ITERS]; };
 
+// NKS = 0: the plain `up` convolution.  NKS = C/16 in {2, 4, 8}: up + fuse composed, the skip term (K = C = 16 NKS) in the epilogue.
+template <int NKS>
 __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[UP_LDS];
     const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -119,7 +150,8 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
     };
 
     f32x16_t acc[4][2];
-    const float* bias_lds = reinterpret_cast<const float*>(smem + 2 * UP_BUF);
+    const float* bias_lds = reinterpret_cast<const float*>(smem + UP_BIAS_OFF);
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
     UpRegs R;          // one register set: holds stage s+1's input; chunk i goes to LDS and is reloaded with stage s+2 in place
 
     // ---- epilogue: accumulator i of lane (r, h) of parity (pa, pb), row m is output pixel (2*(ty*16 + 2*wave + m) + pa,
@@ -130,6 +162,102 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
         char* obase = reinterpret_cast<char*>(a.out) + (size_t)it.img * a.Hout * a.Wout * a.cout * 2;
         const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.Hout * a.Wout * a.cout * 2, 0x00020000);
         const int ly = it.ty * UP_TH + w_e * 2, lx = it.tx * UP_TW + r_e;       // low-res coordinates of row m = 0
+        if constexpr (NKS > 0) {
+            // ---- fused form: skip term by MFMA, bf16 stores, GroupNorm partials ------------------------------------------------
+            constexpr int NKG = NKS / 2;              // units (two k-steps = 32 skip channels) per (parity, row)
+            constexpr int U = 8 * NKG;                // unit u = (par * 2 + m) * NKG + kg
+            constexpr int D = 4;                      // units in flight: 8 x 16 B per lane
+            const int C = a.cout;
+            const char* sbase = reinterpret_cast<const char*>(a.in1) + (size_t)it.img * a.Hout * a.Wout * C * 2;
+            // loads past the image's last byte return zero; a pixel past the right edge reads a neighbour's bytes: either way the
+            // MFMA column (= that pixel) is never stored nor counted
+            const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(sbase), 0, a.Hout * a.Wout * C * 2, 0x00020000);
+            const unsigned rowB = (unsigned)(a.Wout * C * 2), pxB = (unsigned)(C * 2);
+            const unsigned s_off = (unsigned)((2 * ly) * a.Wout + 2 * lx) * pxB + (unsigned)(h_e * 16);
+            const bool inb[2] = {ly < a.Hin && lx < a.Win, ly + 1 < a.Hin && lx < a.Win};
+            const unsigned char* skw = smem + UP_SKW_OFF + (h_e * 32 + r_e) * 16;      // + ks * 1024
+            const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+            u32x4_t ring[D][2];
+            float ssum[4] = {0.f, 0.f, 0.f, 0.f}, qsum[4] = {0.f, 0.f, 0.f, 0.f};   // per cout quad of this lane-half: i = 4k .. 4k + 3
+            auto issue = [&](auto u_tag) __attribute__((always_inline)) {
+                constexpr int u = decltype(u_tag)::value;
+                constexpr int pm = u / NKG, kg = u % NKG, par = pm >> 1, m = pm & 1, pa = par >> 1, pb = par & 1;
+                const unsigned off = s_off + (unsigned)(2 * m + pa) * rowB + (unsigned)pb * pxB + (unsigned)(kg * 64);
+                ring[u % D][0] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, off, 0, 0);
+                ring[u % D][1] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, off + 32u, 0, 0);
+            };
+            auto consume = [&](auto u_tag) __attribute__((always_inline)) {
+                constexpr int u = decltype(u_tag)::value;
+                constexpr int pm = u / NKG, kg = u % NKG, par = pm >> 1, m = pm & 1;
+                const bf16x8_t w0 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(skw + (2 * kg) * 1024));
+                const bf16x8_t w1 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(skw + (2 * kg + 1) * 1024));
+                acc[par][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, __builtin_bit_cast(bf16x8_t, ring[u % D][0]), acc[par][m], 0, 0, 0);
+                acc[par][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, __builtin_bit_cast(bf16x8_t, ring[u % D][1]), acc[par][m], 0, 0, 0);
+            };
+            auto finish = [&](auto par_tag) __attribute__((always_inline)) {
+                constexpr int par = decltype(par_tag)::value;
+                constexpr int pa = par >> 1, pb = par & 1;
+                const int ox = 2 * lx + pb;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int oy = 2 * (ly + m) + pa;
+                    const unsigned off = ((unsigned)((oy * a.Wout + ox) * a.cout + it.nb * UP_NT) << 1) + (unsigned)(h_e * 16);
+                    const f32x16_t& c = acc[par][m];
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp) {
+                        unsigned w[4] = {up_pack(c[8 * pp + 0], c[8 * pp + 1]), up_pack(c[8 * pp + 2], c[8 * pp + 3]),
+                                         up_pack(c[8 * pp + 4], c[8 * pp + 5]), up_pack(c[8 * pp + 6], c[8 * pp + 7])};
+                        const u32x4_t wv4 = {w[0], w[1], w[2], w[3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(wv4, orsrc, inb[m] ? off + (unsigned)(pp * 32) : 0xffffffffu, 0, 0);
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const bf16x2_t wv = __builtin_bit_cast(bf16x2_t, inb[m] ? w[d] : 0u);     // the statistics are those of the STORED values
+                            ssum[2 * pp + (d >> 1)] = __builtin_amdgcn_fdot2_f32_bf16(wv, ones, ssum[2 * pp + (d >> 1)], false);
+                            qsum[2 * pp + (d >> 1)] = __builtin_amdgcn_fdot2_f32_bf16(wv, wv, qsum[2 * pp + (d >> 1)], false);
+                        }
+                    }
+                }
+            };
+            auto unit = [&](auto u_tag) __attribute__((always_inline)) {
+                constexpr int u = decltype(u_tag)::value;
+                consume(u_tag);
+                if constexpr (u + D < U) issue(std::integral_constant<int, u + D>{});
+                if constexpr ((u + 1) % (2 * NKG) == 0) finish(std::integral_constant<int, u / (2 * NKG)>{});
+            };
+            issue(std::integral_constant<int, 0>{}); issue(std::integral_constant<int, 1>{});
+            issue(std::integral_constant<int, 2>{}); issue(std::integral_constant<int, 3>{});
+            up_static_for<0, U>(unit);
+            // GroupNorm partials of the item: quad k of lane-half h is couts 16 (k >> 1) + 8 h + 4 (k & 1) .. + 3 of the block
+            float rv[8] = {ssum[0], qsum[0], ssum[1], qsum[1], ssum[2], qsum[2], ssum[3], qsum[3]};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rv[i] = up_ror_add<1>(rv[i]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rv[i] = up_ror_add<2>(rv[i]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rv[i] = up_ror_add<4>(rv[i]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rv[i] = up_ror_add<8>(rv[i]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rv[i] = up_swap16_add(rv[i]);
+            float* red = reinterpret_cast<float*>(smem + UP_RED_OFF);
+            if (r_e == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    *reinterpret_cast<float2*>(red + (w_e * 8 + (k >> 1) * 4 + 2 * h_e + (k & 1)) * 2) = make_float2(rv[2 * k], rv[2 * k + 1]);
+            }
+            __syncthreads();
+            const int G = a.group_size, qpg = G >> 2, ngl = UP_NT / G;       // quads per group (1, 2 or 4), groups in the item's 32 couts
+            if (tid < ngl) {
+                float sv = 0.f, qv = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < qpg) { sv += red[(w * 8 + tid * qpg + k) * 2 + 0]; qv += red[(w * 8 + tid * qpg + k) * 2 + 1]; }
+                float* st = a.stats + (((size_t)it.img * tiles_per_img + it.tile) * 8 + (it.nb * UP_NT) / G + tid) * 2;
+                st[0] = sv; st[1] = qv;
+            }
+        } else {
 #pragma unroll
         for (int par = 0; par < 4; ++par) {
             const int pa = par >> 1, pb = par & 1;
@@ -147,6 +275,7 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
                     __builtin_amdgcn_raw_buffer_store_b128(wv4, orsrc, inb ? off + (unsigned)(pp * 32) : 0xffffffffu, 0, 0);
                 }
             }
+        }
         }
 #pragma unroll
         for (int par = 0; par < 4; ++par)
@@ -168,7 +297,8 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
     };
     auto stage = [&](int s, auto par_tag, auto last_tag) {
         constexpr int PAR = decltype(par_tag)::value;
-        constexpr bool LAST = decltype(last_tag)::value;      // the item's last stage: epilogue before the barrier
+        constexpr int LASTV = decltype(last_tag)::value;      // 1: the item's last stage (epilogue before the barrier); 2: the one before it
+        constexpr bool LAST = LASTV == 1, PRELAST = LASTV == 2;
         const unsigned char* ib = smem + PAR * UP_BUF;
         uint4* in_nxt = reinterpret_cast<uint4*>(smem + (PAR ^ 1) * UP_BUF);
         const unsigned char* wb = smem + PAR * UP_BUF + UP_IN_BYTES + b_off;
@@ -231,6 +361,14 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
                     up_glds16(ws + (size_t)(cbase + lane) * 16, w_nxt_lds + cbase * 16);
                 }
             }
+            // fused form: the skip weights of this item's cout block (NKS KB) for the epilogue of the NEXT stage, one wave
+            // instruction per KB; published by this stage's barrier, and the previous item's epilogue ended before the last one
+            if constexpr (NKS > 0 && PRELAST && g == 1) {
+                const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+                if (wave_u < NKS)
+                    up_glds16(reinterpret_cast<const unsigned char*>(a.w1) + ((size_t)sq0.it.nb * NKS + wave_u) * 1024 + lane * 16,
+                              smem_lds + UP_SKW_OFF + wave_u * 1024);
+            }
             __builtin_amdgcn_sched_barrier(0);
         };
         read_group(std::integral_constant<int, 0>{}, afr[0], bfr[0]);
@@ -249,7 +387,7 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
 
     // ---- prologue: stage 0 -> LDS buffer 0, stage 1 -> registers -----------------------------------------------------------
     {
-        float* bl = reinterpret_cast<float*>(smem + 2 * UP_BUF);
+        float* bl = reinterpret_cast<float*>(smem + UP_BIAS_OFF);
         if (tid < a.cout && tid < 256) bl[tid] = a.bias[tid];
         load_stage(sq0, R);
         const uint4* ws = reinterpret_cast<const uint4*>(wslab(sq0));
@@ -267,11 +405,11 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
     for (int k = 0; k < my_items; ++k) {
         init_acc(sq0.it.nb);
         for (int kc = 0; kc + 2 < nkc; kc += 2) {
-            stage(s, std::integral_constant<int, 0>{}, std::false_type{}); ++s;
-            stage(s, std::integral_constant<int, 1>{}, std::false_type{}); ++s;
+            stage(s, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); ++s;
+            stage(s, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}); ++s;
         }
-        stage(s, std::integral_constant<int, 0>{}, std::false_type{}); ++s;
-        stage(s, std::integral_constant<int, 1>{}, std::true_type{}); ++s;
+        stage(s, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}); ++s;
+        stage(s, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}); ++s;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may be in flight when the workgroup's LDS is released
 }
@@ -279,15 +417,21 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
 }  // namespace
 
 // a.in0 = low-res tensor [nimg][Hin (+halo)][Win][Cin], a.out = [nimg][2*Hin][2*Win][cout]; a.nkc = Cin/32 (even), a.nblocks =
-// cout/32, a.tiles_x/y = low-res tiles of 16x32; a.w = sub-pixel slabs [nblock][kc][parity][kk][32 permuted rows][8]
+// cout/32, a.tiles_x/y = low-res tiles of 16x32; a.w = sub-pixel slabs [nblock][kc][parity][kk][32 permuted rows][8].
+// Fused with the 1x1 `fuse` (a.in1 != null): a.w / a.bias = the composed weights, a.in1 = skip tensor [nimg][2*Hin][2*Win][cout]
+// (first real row), a.w1 = skip weights [nblock][ks = cout/16][h][32 permuted rows][8], a.stats = partials per (image, low-res tile).
 void conv_up_subpixel_launch(const ConvArgs& a, hipStream_t stream) {
     if (a.nkc < 2 || (a.nkc & 1) || a.cout > 256) fail(IRE_ERR_INTERNAL, "internal: conv_up_subpixel shape");
+    if (a.in1 && (!a.w1 || !a.stats || (a.cout != 32 && a.cout != 64 && a.cout != 128))) fail(IRE_ERR_INTERNAL, "internal: fused conv_up arguments");
     const int items = a.tiles_x * a.tiles_y * a.nimg * a.nblocks;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int grid = items < cus ? items : cus;
-    hipLaunchKernelGGL(conv_up_kernel, dim3(grid), dim3(UP_THREADS), 0, stream, a);
+    if (!a.in1) hipLaunchKernelGGL(conv_up_kernel<0>, dim3(grid), dim3(UP_THREADS), 0, stream, a);
+    else if (a.cout == 32) hipLaunchKernelGGL(conv_up_kernel<2>, dim3(grid), dim3(UP_THREADS), 0, stream, a);
+    else if (a.cout == 64) hipLaunchKernelGGL(conv_up_kernel<4>, dim3(grid), dim3(UP_THREADS), 0, stream, a);
+    else hipLaunchKernelGGL(conv_up_kernel<8>, dim3(grid), dim3(UP_THREADS), 0, stream, a);
     IRE_HIP(hipGetLastError());
 }
 

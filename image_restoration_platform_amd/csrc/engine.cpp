@@ -90,6 +90,7 @@ Engine::Engine(const ire_config& cfg) {
     if (const char* v = std::getenv("IRE_W4_FUSED_MINC")) w4_fused_min_c_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_UP_RB_MINC")) up_rb_min_c_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_UP_SUBPIX")) up_subpixel_ = std::atoi(v);
+    if (const char* v = std::getenv("IRE_UP_FUSE")) up_fuse_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_HEAD_RB")) head_rb_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_DOWN_RB")) down_rb_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_FP8_MX")) fp8_mx_ = std::atoi(v);
@@ -362,6 +363,70 @@ ConvW Engine::make_conv(ConvKind kind, const std::string& wname, const std::stri
     return c;
 }
 
+// `up` (nearest x2 -> 3x3, 2C -> C) followed by `fuse` (1x1 over concat(up, skip), 2C -> C) with nothing non-linear between
+// them is ONE convolution plus a 1x1 over the skip tensor:
+//   fuse(concat(up(x), skip)) = (Wf_up . Wup) * x_up  +  Wf_skip . skip  +  (Wf_up . b_up + b_f),   Wf = [Wf_up | Wf_skip].
+// The composition is done once here in double, then the sub-pixel pre-sums of conv_up.hip, then ONE rounding to bf16.
+void Engine::make_up_fused(ConvW& up, const std::string& sl) {
+    const int C = up.cout, cin = up.cin;
+    if (up.kind != CONV_UP || up.d_wu == nullptr || (C != 32 && C != 64 && C != 128)) return;
+    auto wu = host_w_.find("up" + sl + ".w"), bu = host_w_.find("up" + sl + ".b");
+    auto wf = host_w_.find("fuse" + sl + ".w"), bf = host_w_.find("fuse" + sl + ".b");
+    if (wu == host_w_.end() || bu == host_w_.end() || wf == host_w_.end() || bf == host_w_.end()) return;
+    const float* Wu = wu->second.second.data();        // [C][cin][3][3]
+    const float* Wf = wf->second.second.data();        // [C][2C]
+    if ((int)wf->second.second.size() != C * 2 * C) return;
+    std::vector<double> Wc((size_t)C * cin * 9, 0.0);
+    for (int co = 0; co < C; ++co)
+        for (int m = 0; m < C; ++m) {
+            const double f = Wf[(size_t)co * 2 * C + m];
+            const float* src = Wu + (size_t)m * cin * 9;
+            double* dst = Wc.data() + (size_t)co * cin * 9;
+            for (int k = 0; k < cin * 9; ++k) dst[k] += f * (double)src[k];
+        }
+    std::vector<float> bc(C);
+    for (int co = 0; co < C; ++co) {
+        double b = bf->second.second[co];
+        for (int m = 0; m < C; ++m) b += (double)Wf[(size_t)co * 2 * C + m] * (double)bu->second.second[m];
+        bc[co] = (float)b;
+    }
+    auto perm = [](int n) { return (n & ~12) | ((n & 4) << 1) | ((n & 8) >> 1); };
+    const int nbu = C / 32, nku = cin / 32;
+    std::vector<unsigned short> arru((size_t)nbu * nku * 4 * 16 * 32 * 8, 0);
+    auto lo_of = [](int par, int d) { return par == 0 ? (d == 0 ? 0 : 1) : (d == 0 ? 0 : 2); };
+    auto hi_of = [](int par, int d) { return par == 0 ? (d == 0 ? 0 : 2) : (d == 0 ? 1 : 2); };
+    for (int nb = 0; nb < nbu; ++nb)
+        for (int kc = 0; kc < nku; ++kc)
+            for (int par = 0; par < 4; ++par)
+                for (int kk = 0; kk < 16; ++kk) {
+                    const int pa = par >> 1, pb = par & 1, tap4 = kk >> 2, c8 = kk & 3, dy = tap4 >> 1, dx = tap4 & 1;
+                    for (int n = 0; n < 32; ++n)
+                        for (int e = 0; e < 8; ++e) {
+                            const int co = nb * 32 + perm(n), ci = kc * 32 + c8 * 8 + e;
+                            double sum = 0.0;
+                            for (int ky = lo_of(pa, dy); ky <= hi_of(pa, dy); ++ky)
+                                for (int kx = lo_of(pb, dx); kx <= hi_of(pb, dx); ++kx) sum += Wc[((size_t)co * cin + ci) * 9 + ky * 3 + kx];
+                            arru[(((((size_t)nb * nku + kc) * 4 + par) * 16 + kk) * 32 + n) * 8 + e] = f32_to_bf16((float)sum);
+                        }
+                }
+    const int nks = C / 16;
+    std::vector<unsigned short> arrs((size_t)nbu * nks * 2 * 32 * 8, 0);
+    for (int nb = 0; nb < nbu; ++nb)
+        for (int ks = 0; ks < nks; ++ks)
+            for (int hh = 0; hh < 2; ++hh)
+                for (int n = 0; n < 32; ++n)
+                    for (int e = 0; e < 8; ++e)
+                        arrs[((((size_t)nb * nks + ks) * 2 + hh) * 32 + n) * 8 + e] =
+                            f32_to_bf16(Wf[(size_t)(nb * 32 + perm(n)) * 2 * C + C + ks * 16 + hh * 8 + e]);
+    up.d_wuf = (unsigned short*)dalloc(arru.size() * 2);
+    up.d_wsk = (unsigned short*)dalloc(arrs.size() * 2);
+    up.d_bias_uf = (float*)dalloc(C * 4);
+    net_.allocs.push_back(up.d_wuf); net_.allocs.push_back(up.d_wsk); net_.allocs.push_back(up.d_bias_uf);
+    IRE_HIP(hipMemcpy(up.d_wuf, arru.data(), arru.size() * 2, hipMemcpyHostToDevice));
+    IRE_HIP(hipMemcpy(up.d_wsk, arrs.data(), arrs.size() * 2, hipMemcpyHostToDevice));
+    IRE_HIP(hipMemcpy(up.d_bias_uf, bc.data(), C * 4, hipMemcpyHostToDevice));
+}
+
 GNW Engine::make_gn(const std::string& prefix, int C, int level) {
     GNW g;
     g.C = C; g.level = level;
@@ -437,6 +502,7 @@ void Engine::load_weights(const void* blob, size_t bytes) {
         const std::string s = std::to_string(l);
         net_.up[l] = make_conv(CONV_UP, "up" + s + ".w", "up" + s + ".b", kWidths[l + 1], kWidths[l]);
         net_.fuse[l] = make_conv(CONV_FUSE, "fuse" + s + ".w", "fuse" + s + ".b", 2 * kWidths[l], kWidths[l]);
+        make_up_fused(net_.up[l], s);
         for (int i = 0; i < 2; ++i) net_.dec[l][i] = make_rb("dec" + s + ".rb" + std::to_string(i), kWidths[l], l);
     }
     net_.head_gn = make_gn("head.gn", 32, 0);
@@ -650,8 +716,9 @@ void Engine::build_program() {
     auto conv = [&](const ConvW& cw, int in0, int in1, int resid, int out, int lin, int lout, bool use_ab, const std::string& name) {
         Op o; o.kind = Op::CONV; o.cw = &cw; o.in0 = in0; o.in1 = in1; o.resid = resid; o.out = out; o.lin = lin; o.lout = lout;
         o.use_ab = use_ab; o.name = name;
-        o.halo_out = cw.kind != CONV_UP && cw.kind != CONV_HEAD;         // `up` feeds the 1x1 fuse only, the head writes pixels
-        o.stats_out = cw.kind != CONV_UP && cw.kind != CONV_HEAD;
+        const bool upf = cw.kind == CONV_UP && in1 != BUF_NONE;           // `up` composed with `fuse`: its output is what fuse's was
+        o.halo_out = (cw.kind != CONV_UP || upf) && cw.kind != CONV_HEAD;   // a plain `up` feeds the 1x1 fuse only, the head writes pixels
+        o.stats_out = (cw.kind != CONV_UP || upf) && cw.kind != CONV_HEAD;
         program_.push_back(o);
     };
     auto act = [&](int in0, int out, int l) { Op o; o.kind = Op::ACT; o.in0 = in0; o.out = out; o.lin = o.lout = l; program_.push_back(o); };
@@ -682,8 +749,13 @@ void Engine::build_program() {
     int deep = buf_id(3, 2);
     for (int l = 2; l >= 0; --l) {
         const std::string sl = std::to_string(l);
-        conv(net_.up[l], deep, BUF_NONE, BUF_NONE, buf_id(l, 0), l + 1, l, false, "up" + sl);
-        conv(net_.fuse[l], buf_id(l, 0), buf_id(l, 4), BUF_NONE, buf_id(l, 2), l, l, false, "fuse" + sl);
+        const bool upf = v2 && up_fuse_ && up_subpixel_ && net_.up[l].d_wuf != nullptr && net_.up[l].cout >= up_rb_min_c_;
+        if (upf) {
+            conv(net_.up[l], deep, buf_id(l, 4), BUF_NONE, buf_id(l, 2), l + 1, l, false, "fuse" + sl);     // one kernel, the `up` tensor never exists
+        } else {
+            conv(net_.up[l], deep, BUF_NONE, BUF_NONE, buf_id(l, 0), l + 1, l, false, "up" + sl);
+            conv(net_.fuse[l], buf_id(l, 0), buf_id(l, 4), BUF_NONE, buf_id(l, 2), l, l, false, "fuse" + sl);
+        }
         resblock(net_.dec[l][0], buf_id(l, 2), buf_id(l, 1), buf_id(l, 3), l, "dec" + sl + ".rb0");
         resblock(net_.dec[l][1], buf_id(l, 3), buf_id(l, 1), buf_id(l, 0), l, "dec" + sl + ".rb1");
         deep = buf_id(l, 0);
@@ -733,6 +805,7 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     const bool rb = (cw.kind == CONV_RB1 || cw.kind == CONV_RB2);
     const bool up_rb = (cw.kind == CONV_UP) && rb_tile_h_ == kRbTileH && cw.cout >= up_rb_min_c_;
     const bool up_sub = up_rb && up_subpixel_ && cw.d_wu != nullptr;       // sub-pixel form: tiles and halo rows on the LOW-res grid
+    const bool up_fused = up_sub && op.in1 != BUF_NONE;                     // composed with the 1x1 `fuse` (build_program)
     const bool head_rb = cw.kind == CONV_HEAD && rb_tile_h_ == kRbTileH && head_rb_ && cw.d_wp != nullptr;    // the head on the pipelined kernel
     const bool down_rb = cw.kind == CONV_DOWN && rb_tile_h_ == kRbTileH && down_rb_ && cw.d_wd != nullptr;    // stride-2 convs by pixel phase
     const int th = (rb || up_rb || head_rb || down_rb) ? rb_tile_h_ : conv_tile_h(cw.kind);
@@ -746,9 +819,11 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     if (op.stats_out) {
         // partials are indexed by the GLOBAL tile: a strip writes its tiles at its offset (strip starts are multiples of the
         // tile height at every level: checked by the strip planner), so the finalize sees exactly the whole-image layout
-        const int ty0 = (g.y0 >> op.lout) / th;
+        // (the fused `up` writes one partial per LOW-res tile: its items are 32 x 64 output pixels)
+        const int sl = up_fused ? op.lin : op.lout;
+        const int ty0 = (g.y0 >> sl) / th;
         a.stats = R.stats + (size_t)ty0 * a.tiles_x * 16;
-        R.stat_parts = a.tiles_x * ceil_div(g.H >> op.lout, th);
+        R.stat_parts = a.tiles_x * ceil_div(g.H >> sl, th);
     }
     a.nimg = g.nimg; a.nblocks = cw.nblocks;
     a.group_size = std::max(1, a.cout / 8);
@@ -761,9 +836,10 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     }
     const int taps = (cw.kind == CONV_FUSE) ? 1 : 9;
     const double px = (double)g.nimg * Hout * Wout;
-    const double flops = 2.0 * taps * cw.cin * cw.cout * px;
+    double flops = 2.0 * taps * cw.cin * cw.cout * px;
     const double in_px = (double)g.nimg * Hin * Win;
     double bytes = in_px * cw.cin * (cw.kind == CONV_STEM ? 1 : 2) + px * cw.cout * (cw.kind == CONV_HEAD ? 1 : 2);
+    if (up_fused) { flops += 2.0 * 2 * cw.cout * cw.cout * px; bytes += px * cw.cout * 2; }   // the algorithmic work of `fuse` rides along: 1x1 over 2C channels, the skip tensor read
     if (cw.kind == CONV_RB2) bytes += px * cw.cout * 2;
     if (cw.kind == CONV_HEAD) bytes += px * 3;
     int fam = FAM_CONV3;
@@ -785,7 +861,13 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
         conv_w4_launch(cw.kind == CONV_RB2, a, R.stream);
     } else if (head_rb) { a.w = cw.d_wp; conv_head_launch(a, R.stream); }
     else if (down_rb) { a.w = cw.d_wd; a.nkc = cw.cin / 32; a.nblocks = cw.cout / 64; conv_down_launch(a, R.stream); }
-    else if (up_sub) { a.w = cw.d_wu; a.nkc = cw.cin / 32; a.nblocks = cw.cout / 32; conv_up_subpixel_launch(a, R.stream); }
+    else if (up_fused) {
+        a.w = cw.d_wuf; a.w1 = cw.d_wsk; a.bias = cw.d_bias_uf; a.nkc = cw.cin / 32; a.nblocks = cw.cout / 32;
+        a.in1 = in_ptr(op.in1) + (size_t)g.halo * Wout * cw.cout;      // the skip tensor is read at output pixels only: first real row
+        a.cin1 = cw.cout;
+        conv_up_subpixel_launch(a, R.stream);
+    }
+    else if (up_sub) { a.in1 = nullptr; a.w = cw.d_wu; a.nkc = cw.cin / 32; a.nblocks = cw.cout / 32; conv_up_subpixel_launch(a, R.stream); }
     else if (up_rb) { if (cw.d_wp) a.w = cw.d_wp; conv_up_launch(a, R.stream); }
     else if (rb && rb_tile_h_ == kRbTileH) { if (cw.d_wp) a.w = cw.d_wp; conv_rb_launch(cw.kind == CONV_RB2, /*fused_act=*/a.ab != nullptr, a, R.stream); }
     else conv_launch(cw.kind, a, R.stream);

@@ -31,6 +31,10 @@ struct ConvW {
     unsigned short* d_w4 = nullptr;  // second arrangement for conv_w4.hip (C >= 128 ResBlock convs): 16-channel stages, 128-cout blocks
     unsigned short* d_wd = nullptr;  // CONV_DOWN by pixel phase (conv_down.hip): [nblock64][kc32][phase: 1+2+2+4 taps][tap*4 + c8][64][8]
     unsigned short* d_wu = nullptr;  // CONV_UP as a sub-pixel conv (conv_up.hip): [nblock32][kc32][parity][kk][32][8], taps pre-summed per parity
+    // CONV_UP composed with the level's 1x1 `fuse` (engine.cpp::make_up_fused; conv_up.hip fused form)
+    unsigned short* d_wuf = nullptr; // sub-pixel slabs of (Wf_up . Wup), layout of d_wu
+    unsigned short* d_wsk = nullptr; // skip half of the fuse weights as MFMA A fragments: [nblock32][ks = C/16][h][32 permuted rows][8]
+    float* d_bias_uf = nullptr;      // Wf_up . b_up + b_f
     unsigned char* d_w8x = nullptr;  // IRE_PRECISION_FP8, K = 64 form (conv_f8.hip): [nblock128][kc32][tap][half][128][16] e4m3
     unsigned char* d_w8 = nullptr;   // IRE_PRECISION_FP8: the conv_w4 slabs as OCP e4m3, one scale per output channel
     float* d_oscale = nullptr;       // [cout] weight scale / activation scale (accumulator -> output)
@@ -184,6 +188,7 @@ private:
     void prof_end(hipStream_t s);
     void capture(const char* name, const unsigned short* d, size_t count, hipStream_t s);
     ConvW make_conv(ConvKind kind, const std::string& wname, const std::string& bname, int cin, int cout);
+    void make_up_fused(ConvW& up, const std::string& level);
     GNW make_gn(const std::string& prefix, int C, int level);
     RBW make_rb(const std::string& prefix, int C, int level);
     void* dalloc(size_t bytes);
@@ -199,6 +204,7 @@ private:
     int fp8_mx_ = 1;              // fp8: the block-scaled K = 64 MFMA (conv_f8.hip); IRE_FP8_MX=0: the same-rate 32x32x16 fp8 form in conv_w4.hip
     int down_rb_ = 1;             // stride-2 `down` convs on conv_down.hip's pipelined phase kernel (IRE_DOWN_RB=0: the v1 kernel)
     int head_rb_ = 1;             // the 32 -> 3 head conv on conv_rb.hip's pipelined kernel (IRE_HEAD_RB=0: the v1 kernel)
+    int up_fuse_ = 1;             // `up` + 1x1 `fuse` as ONE composed convolution with the skip term in conv_up.hip's epilogue (IRE_UP_FUSE=0: two kernels)
     int up_subpixel_ = 1;         // `up` convs as sub-pixel convolutions on the low-res grid (IRE_UP_SUBPIX=0: nearest x2 + 3x3 on conv_rb.hip)
     int up_rb_min_c_ = 32;        // `up` convs with cout >= this run on conv_rb.hip (IRE_UP_RB_MINC), the rest on the v1 kernel
     int prio_young_ = 0;          // static s_setprio for waves 4-7 of conv_rb (A/B'd: it only swaps which half waits)

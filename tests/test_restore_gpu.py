@@ -37,18 +37,27 @@ LAYERS = ["stem"] + [f"enc{l}.rb{i}{s}" for l in range(4) for i in range(2) for 
          [f"dec{l}.rb{i}{s}" for l in (2, 1, 0) for i in range(2) for s in (".h", "")]
 
 
-@pytest.mark.parametrize("h,w,n", [(64, 96, 2), (72, 136, 1)])
-def test_every_layer_tracks_the_bf16_emulating_oracle(engine, weights0, h, w, n):
+@pytest.mark.parametrize("h,w,n,fused", [(64, 96, 2, True), (72, 136, 1, True), (72, 136, 1, False)])
+def test_every_layer_tracks_the_bf16_emulating_oracle(engine, weights0, h, w, n, fused, monkeypatch):
     """Layer-by-layer: catches indexing bugs an end-to-end tolerance could hide.  (72,136) has ragged
-    tiles at every level (9x17 at 1/8 scale)."""
+    tiles at every level (9x17 at 1/8 scale).  By default `up` and the 1x1 `fuse` run as ONE composed convolution
+    (conv_up.hip fused form): the `up` tensor does not exist and `fuse{l}` is that kernel's output; with IRE_UP_FUSE=0 the
+    two layers run as two kernels and both tensors are checked."""
+    from image_restoration_platform_amd.engine import Engine
     imgs = synth.batch(n, h, w)
     sc = _scores(imgs)
+    own = None
+    if not fused:
+        monkeypatch.setenv("IRE_UP_FUSE", "0")
+        engine = own = Engine(device_index=0, max_batch=8)
     engine.debug_capture(True)
     try:
         out = engine.restore(imgs, scores=sc)
         cap = {}
         ref = onet.restore(imgs, sc, weights0, emulate_bf16=True, capture=cap)
         for nm in LAYERS:
+            if fused and nm.startswith("up"):
+                continue
             a, r = engine.activation(nm), cap[nm].reshape(-1)
             assert a.size == r.size, nm
             rel = np.abs(a - r).mean() / (np.abs(r).mean() + 1e-9)
@@ -56,6 +65,8 @@ def test_every_layer_tracks_the_bf16_emulating_oracle(engine, weights0, h, w, n)
             assert np.abs(a - r).max() < 0.25 * (np.abs(r).max() + 1e-9), nm
     finally:
         engine.debug_capture(False)
+        if own is not None:
+            own.close()
     assert np.abs(out.astype(np.int32) - ref.astype(np.int32)).max() <= 2
 
 
@@ -69,7 +80,7 @@ def test_end_to_end_vs_fp32_oracle(engine, weights0, h, w, n):
 
 
 @pytest.mark.parametrize("env", [{"IRE_W4": "0"}, {"IRE_W4_WAVES": "4", "IRE_ACT_SPLIT_MINC": "128"}, {"IRE_W4_WAVES": "4"}, {"IRE_CONV_V1": "1"}, {"IRE_UP_RB_MINC": "64"},
-                                 {"IRE_ACT_SPLIT_MINC": "64"}, {"IRE_ACT_SPLIT_MINC": "128"}, {"IRE_UP_SUBPIX": "0"}, {"IRE_DOWN_RB": "0", "IRE_HEAD_RB": "0"},
+                                 {"IRE_ACT_SPLIT_MINC": "64"}, {"IRE_ACT_SPLIT_MINC": "128"}, {"IRE_UP_SUBPIX": "0"}, {"IRE_UP_FUSE": "0"}, {"IRE_DOWN_RB": "0", "IRE_HEAD_RB": "0"},
                                  {"IRE_W4_FUSED_MINC": "100000", "IRE_ACT_SPLIT_MINC": "256"}, {"IRE_W4_FUSED_MINC": "100000"}])
 def test_alternate_kernel_schedules_agree(engine, weights0, env, monkeypatch):
     """Every A/B switch of the engine (conv_rb instead of conv_w4 at C >= 128, the 4-wave conv_w4, the v1 conv schedule, the
