@@ -16,6 +16,7 @@
 // planes per pixel / per cout row, so every fragment is two conflict-free ds_read_b128.
 #include "conv_mfma.hpp"
 #include "persist.hpp"
+#include "gn_fold.hpp"
 
 namespace ire {
 
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(F8_THREADS) void conv_f8_kernel(ConvArgs a) {
     const int my_items = cursor.my_items;
     const int S = cursor.S;
     if (S == 0) return;
+    if (a.gn_stats) gn_fold(a, smem, cursor.first_img, cursor.last_img);     // GroupNorm finalize of the input tensor, folded in (gn_fold.hpp)
     using StageInfo = PersistStage;
     StageInfo sq0 = cursor.cur, sq1 = cursor.next(), sq2 = cursor.next();
 

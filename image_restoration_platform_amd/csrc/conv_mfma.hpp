@@ -27,6 +27,15 @@ struct ConvArgs {
     const unsigned short* w1;    // conv_up.hip fused with `fuse`: skip weights [nblock32][ks][h][32][8] bf16, else null
     const float* bias;           // [cout]
     const float2* ab;            // [nimg][cin0] GroupNorm+FiLM coefficients (PRO_GN)
+    // GroupNorm finalize folded into this kernel's prologue (gn_fold.hpp): when gn_stats != null every workgroup first reduces
+    // the partials of the image(s) it reads and writes `ab_w` (== ab); null: `ab` was filled by gn_finalize_kernel
+    const float* gn_stats;       // [nimg][gn_parts][8][2] partials of the INPUT tensor
+    int gn_parts, gn_hw;         // partials per image; pixels per image of the input tensor
+    const float* gn_gamma;       // [cin0]
+    const float* gn_beta;
+    const float* gn_film;        // [nimg][gn_film_stride] FiLM (scale | shift) rows, or null
+    int gn_film_stride, gn_film_off;
+    float2* ab_w;
     const unsigned short* resid; // [nimg][Hout][Wout][cout] bf16 (CONV_RB2)
     unsigned short* out;         // [nimg][Hout][Wout][cout] bf16
     const unsigned char* u8_in;  // CONV_HEAD: original image

@@ -17,6 +17,7 @@
 // Roofline: MFMA for C >= 128 (2*9*C*C flop per pixel), HBM for C = 32/64 (4C..6C B per pixel).
 #include "conv_mfma.hpp"
 #include "persist.hpp"
+#include "gn_fold.hpp"
 
 #include <cstdlib>
 
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
     const int nkc = a.nkc;
     const int S = cursor.S;                                      // stages this workgroup runs
     if (S == 0) return;
+    if (a.gn_stats) gn_fold(a, smem, cursor.first_img, cursor.last_img);     // GroupNorm finalize of the input tensor, folded in (gn_fold.hpp)
     // sq0 = stage s (MFMA + epilogue), sq1 = stage s+1 (weights), sq2 = stage s+2 (prefetch, coefficients)
     using StageInfo = PersistStage;
     StageInfo sq0 = cursor.cur, sq1 = cursor.next(), sq2 = cursor.next();

@@ -16,6 +16,7 @@
 // channels through the current stage buffer (bias, residual, GroupNorm partials, full-line stores).
 #include "conv_mfma.hpp"
 #include "persist.hpp"
+#include "gn_fold.hpp"
 
 #include <cstdlib>
 #include <type_traits>
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
     const int nkc = a.nkc;                         // 16-channel stages per item
     const int S = cursor.S;
     if (S == 0) return;
+    if (a.gn_stats) gn_fold(a, smem, cursor.first_img, cursor.last_img);     // GroupNorm finalize of the input tensor, folded in (gn_fold.hpp)
     using StageInfo = PersistStage;
     StageInfo sq0 = cursor.cur, sq1 = cursor.next(), sq2 = cursor.next();
 

@@ -91,6 +91,7 @@ Engine::Engine(const ire_config& cfg) {
     if (const char* v = std::getenv("IRE_UP_RB_MINC")) up_rb_min_c_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_UP_SUBPIX")) up_subpixel_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_UP_FUSE")) up_fuse_ = std::atoi(v);
+    if (const char* v = std::getenv("IRE_GN_FOLD")) gn_fold_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_HEAD_RB")) head_rb_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_DOWN_RB")) down_rb_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_FP8_MX")) fp8_mx_ = std::atoi(v);
@@ -573,7 +574,7 @@ void Engine::free_workspace() {
         std::memset(L.act, 0, sizeof(L.act));
         std::memset(L.skip, 0, sizeof(L.skip));
         std::memset(L.actbuf, 0, sizeof(L.actbuf));
-        L.stats = nullptr;
+        L.stats = L.stats2 = nullptr;
         L.ab = nullptr;
     }
     ws_imgs_per_lane_ = ws_imgs_cap_ = ws_h_ = ws_w_ = 0;
@@ -587,7 +588,7 @@ size_t Engine::bytes_per_image(int h, int w) const {
         const size_t t = (size_t)(h >> l) * (w >> l) * kWidths[l] * 2;
         b += t * (4 + (l < 3 ? 1 : 0) + (kWidths[l] >= act_split_min_c_ ? 1 : 0));
     }
-    b += (size_t)ceil_div(h, 4) * ceil_div(w, 32) * 16 * 4 + 256 * sizeof(float2);
+    b += 2 * (size_t)ceil_div(h, 4) * ceil_div(w, 32) * 16 * 4 + 256 * sizeof(float2);
     b += (size_t)h * w * 3 * 2;      // d_in_ / d_out_
     return b;
 }
@@ -620,6 +621,7 @@ void Engine::ensure_workspace(int n, int h, int w) {
             }
             const size_t tiles0 = (size_t)ceil_div(h, 4) * ceil_div(w, 32);
             L.stats = (float*)alloc((size_t)per * tiles0 * 16 * 4);
+            L.stats2 = (float*)alloc((size_t)per * tiles0 * 16 * 4);
             L.ab = (float2*)alloc((size_t)per * 256 * sizeof(float2));
         }
     } catch (...) {
@@ -822,8 +824,8 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
         // (the fused `up` writes one partial per LOW-res tile: its items are 32 x 64 output pixels)
         const int sl = up_fused ? op.lin : op.lout;
         const int ty0 = (g.y0 >> sl) / th;
-        a.stats = R.stats + (size_t)ty0 * a.tiles_x * 16;
-        R.stat_parts = a.tiles_x * ceil_div(g.H >> sl, th);
+        float* dst = R.stats_alt ? R.stats_alt : R.stats;         // ping-pong: this conv may still be reading R.stats in its folded finalize
+        a.stats = dst + (size_t)ty0 * a.tiles_x * 16;
     }
     a.nimg = g.nimg; a.nblocks = cw.nblocks;
     a.group_size = std::max(1, a.cout / 8);
@@ -846,9 +848,20 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     if (cw.kind == CONV_FUSE) fam = FAM_CONV1;
     else if (cw.kind == CONV_STEM) fam = FAM_STEM;
     else if (cw.kind == CONV_HEAD) fam = FAM_HEAD;
-    prof_begin(fam, R.stream, flops, bytes);
     // conv_w4: pre-activated input (ab == nullptr) or, from w4_fused_min_c_ up, activation fused into its staging (8-wave form)
     const bool w4 = rb && rb_tile_h_ == kRbTileH && use_w4_ && cw.d_w4 != nullptr && (a.ab == nullptr || cw.cout >= w4_fused_min_c_);
+    if (R.gn_pending) {
+        // the deferred GroupNorm finalize of this conv's input: inside the kernel's prologue where it has one (gn_fold.hpp)
+        const bool folds = a.ab != nullptr && (w4 || head_rb || (rb && rb_tile_h_ == kRbTileH));
+        if (folds) {
+            const GNW& gn = *R.gn_pending;
+            a.gn_stats = R.gn_stats; a.gn_parts = R.gn_parts; a.gn_hw = (g.H >> gn.level) * (g.w >> gn.level);
+            a.gn_gamma = gn.d_gamma; a.gn_beta = gn.d_beta; a.gn_film = R.film; a.gn_film_stride = kFilmDim; a.gn_film_off = kFilmOff[gn.level];
+            a.ab_w = R.ab;
+            R.gn_pending = nullptr;
+        } else flush_gn(R, g);
+    }
+    prof_begin(fam, R.stream, flops, bytes);
     if (w4 && fp8_mx_ && cw.d_w8x != nullptr && a.ab != nullptr) {   // IRE_PRECISION_FP8: the 2x-rate block-scaled fp8 MFMA
         a.fp8 = 1; a.w = reinterpret_cast<const unsigned short*>(cw.d_w8x); a.bias = cw.d_bias8; a.oscale = cw.d_oscale;
         a.nkc = cw.cin / 32; a.nblocks = cw.cout / 128;
@@ -872,22 +885,36 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     else if (rb && rb_tile_h_ == kRbTileH) { if (cw.d_wp) a.w = cw.d_wp; conv_rb_launch(cw.kind == CONV_RB2, /*fused_act=*/a.ab != nullptr, a, R.stream); }
     else conv_launch(cw.kind, a, R.stream);
     prof_end(R.stream);
+    if (op.stats_out) {
+        const int sl = up_fused ? op.lin : op.lout;
+        R.stat_parts = a.tiles_x * ceil_div(g.H >> sl, th);
+        if (R.stats_alt) std::swap(R.stats, R.stats_alt);          // R.stats = the partials produced last
+    }
     if (capture_ && !op.name.empty() && a.out && g.halo == 0) capture(op.name.c_str(), a.out, (size_t)g.nimg * Hout * Wout * cw.cout, R.stream);
+}
+
+void Engine::flush_gn(Run& R, const Geo& g) {
+    const GNW& gn = *R.gn_pending;
+    prof_begin(FAM_GN, R.stream, 0, 0);
+    gn_finalize_launch(R.gn_stats, g.nimg, R.gn_parts, gn.C, (g.H >> gn.level) * (g.w >> gn.level), gn.d_gamma, gn.d_beta, R.film, kFilmDim,
+                       kFilmOff[gn.level], R.ab, R.stream);
+    prof_end(R.stream);
+    R.gn_pending = nullptr;
 }
 
 void Engine::exec_op(Run& R, const Op& op, const Geo& g) {
     switch (op.kind) {
         case Op::GN: {
-            const GNW& gn = *op.gn;
-            prof_begin(FAM_GN, R.stream, 0, 0);
-            gn_finalize_launch(R.stats, g.nimg, R.stat_parts, gn.C, (g.H >> gn.level) * (g.w >> gn.level), gn.d_gamma, gn.d_beta, R.film, kFilmDim,
-                               kFilmOff[gn.level], R.ab, R.stream);
-            prof_end(R.stream);
+            // the partials of the tensor produced last; finalized by the consumer itself (exec_conv) unless that is switched off
+            // or this is a row strip (one finalize over the gathered array serves all strips)
+            R.gn_pending = op.gn; R.gn_stats = R.stats; R.gn_parts = R.stat_parts;
+            if (!gn_fold_ || g.halo) flush_gn(R, g);
             break;
         }
         case Op::ACT: {
             const int l = op.lin, Ht = g.h >> l, Wt = g.w >> l, C = kWidths[l];
             if (g.halo) fail(IRE_ERR_INTERNAL, "internal: the separate activation pass is not available in strip mode");
+            if (R.gn_pending) flush_gn(R, g);
             prof_begin(FAM_GN, R.stream, 0, 2.0 * g.nimg * Ht * Wt * C * 2);
             gn_apply_silu_launch(g.buf[op.in0 >> 3][op.in0 & 7], R.ab, g.buf[op.out >> 3][op.out & 7], g.nimg, Ht * Wt, C, R.stream);
             prof_end(R.stream);
@@ -899,7 +926,7 @@ void Engine::exec_op(Run& R, const Op& op, const Geo& g) {
 
 void Engine::run_network(Lane& L, int nimg, int h, int w, const uint8_t* d_in, uint8_t* d_out, const float* d_film) {
     Run R;
-    R.stream = L.stream; R.stats = L.stats; R.ab = L.ab; R.film = d_film;
+    R.stream = L.stream; R.stats = L.stats; R.stats_alt = L.stats2; R.ab = L.ab; R.film = d_film;
     const Geo g = geo_of_lane(L, nimg, h, w, d_in, d_out);
     for (const Op& op : program_) exec_op(R, op, g);
 }

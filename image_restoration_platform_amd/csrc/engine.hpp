@@ -68,6 +68,7 @@ struct Lane {
     unsigned short* skip[3] = {};
     unsigned short* actbuf[4] = {};   // activated copy of a ResBlock conv input (levels with C >= act_split_min_c)
     float* stats = nullptr;
+    float* stats2 = nullptr;          // second partials array: a conv that finalizes its input's GroupNorm itself (gn_fold.hpp) reads one and writes the other
     float2* ab = nullptr;
 };
 
@@ -94,6 +95,10 @@ struct Run {
     float2* ab = nullptr;             // [image][C] coefficients of the GroupNorm finalized last
     const float* film = nullptr;
     int stat_parts = 0;               // partials per image the last stats-producing conv wrote
+    float* stats_alt = nullptr;       // where the NEXT stats-producing conv writes (ping-pong with `stats`); null: in place (strips)
+    const GNW* gn_pending = nullptr;  // a GroupNorm whose finalize was deferred to its consumer (exec_op GN -> exec_conv)
+    const float* gn_stats = nullptr;  // its partials and their count per image
+    int gn_parts = 0;
 };
 // where one executor instance's rows live: a whole batch (halo = 0) or one row strip of one image (halo = 1)
 struct Geo {
@@ -182,6 +187,7 @@ private:
     void build_program();
     void run_network(Lane& L, int nimg, int h, int w, const uint8_t* d_in, uint8_t* d_out, const float* d_film);
     void exec_op(Run& R, const Op& op, const Geo& g);
+    void flush_gn(Run& R, const Geo& g);       // launch the deferred finalize as its own kernel (consumers without the folded prologue)
     void exec_conv(Run& R, const Op& op, const Geo& g);
     static Geo geo_of_lane(const Lane& L, int nimg, int h, int w, const uint8_t* d_in, uint8_t* d_out);
     void prof_begin(int fam, hipStream_t s, double flops, double bytes);
@@ -204,6 +210,7 @@ private:
     int fp8_mx_ = 1;              // fp8: the block-scaled K = 64 MFMA (conv_f8.hip); IRE_FP8_MX=0: the same-rate 32x32x16 fp8 form in conv_w4.hip
     int down_rb_ = 1;             // stride-2 `down` convs on conv_down.hip's pipelined phase kernel (IRE_DOWN_RB=0: the v1 kernel)
     int head_rb_ = 1;             // the 32 -> 3 head conv on conv_rb.hip's pipelined kernel (IRE_HEAD_RB=0: the v1 kernel)
+    int gn_fold_ = 1;             // GroupNorm finalize inside the consuming conv's prologue (gn_fold.hpp); IRE_GN_FOLD=0: 33 gn_finalize launches per step
     int up_fuse_ = 1;             // `up` + 1x1 `fuse` as ONE composed convolution with the skip term in conv_up.hip's epilogue (IRE_UP_FUSE=0: two kernels)
     int up_subpixel_ = 1;         // `up` convs as sub-pixel convolutions on the low-res grid (IRE_UP_SUBPIX=0: nearest x2 + 3x3 on conv_rb.hip)
     int up_rb_min_c_ = 32;        // `up` convs with cout >= this run on conv_rb.hip (IRE_UP_RB_MINC), the rest on the v1 kernel

@@ -22,6 +22,7 @@ struct PersistCursor {
     int d_img, d_ty, d_tx, d_nb;
     int s;                      // stage the cursor points at
     PersistStage cur;
+    int first_img, last_img;    // images of this workgroup's first and last item (gn_fold.hpp)
 
     __device__ __forceinline__ PersistCursor(int tiles_x_, int tiles_y_, int nimg, int nblocks_, int nkc_) {
         tiles_x = tiles_x_; tiles_y = tiles_y_; nblocks = nblocks_; nkc = nkc_;
@@ -47,6 +48,8 @@ struct PersistCursor {
         cur.it.tile = cur.it.ty * tiles_x + cur.it.tx;
         cur.kc = 0;
         s = 0;
+        first_img = cur.it.img;
+        last_img = my_items > 0 ? (lo + jx + (my_items - 1) * nwx) / nblocks / tiles_per_img : first_img;
     }
     // the stage after `cur` (clamped: past the last stage the cursor stays on it, as the pipelines' harmless over-fetch expects)
     __device__ __forceinline__ PersistStage next() {
