@@ -39,6 +39,9 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
+#ifndef IRE_UP_ABL
+#define IRE_UP_ABL 0      // timing ablations of the fused epilogue (results wrong by design): 1 no skip term, 2 no statistics, 4 no stores, 8 L2 touches in the last stage
+#endif
 constexpr int UP_THREADS = 512;
 constexpr int UP_TH = 16, UP_TW = 32;                 // low-resolution tile
 constexpr int UP_IH = UP_TH + 2, UP_IW = UP_TW + 2;
@@ -166,7 +169,10 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
             // ---- fused form: skip term by MFMA, bf16 stores, GroupNorm partials ------------------------------------------------
             constexpr int NKG = NKS / 2;              // units (two k-steps = 32 skip channels) per (parity, row)
             constexpr int U = 8 * NKG;                // unit u = (par * 2 + m) * NKG + kg
-            constexpr int D = 4;                      // units in flight: 8 x 16 B per lane
+#ifndef IRE_UP_D
+#define IRE_UP_D 4
+#endif
+            constexpr int D = IRE_UP_D;               // units in flight: 2 x 16 B per lane each
             const int C = a.cout;
             const char* sbase = reinterpret_cast<const char*>(a.in1) + (size_t)it.img * a.Hout * a.Wout * C * 2;
             // loads past the image's last byte return zero; a pixel past the right edge reads a neighbour's bytes: either way the
@@ -208,7 +214,9 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
                         unsigned w[4] = {up_pack(c[8 * pp + 0], c[8 * pp + 1]), up_pack(c[8 * pp + 2], c[8 * pp + 3]),
                                          up_pack(c[8 * pp + 4], c[8 * pp + 5]), up_pack(c[8 * pp + 6], c[8 * pp + 7])};
                         const u32x4_t wv4 = {w[0], w[1], w[2], w[3]};
-                        __builtin_amdgcn_raw_buffer_store_b128(wv4, orsrc, inb[m] ? off + (unsigned)(pp * 32) : 0xffffffffu, 0, 0);
+                        if constexpr (!(IRE_UP_ABL & 4)) __builtin_amdgcn_raw_buffer_store_b128(wv4, orsrc, inb[m] ? off + (unsigned)(pp * 32) : 0xffffffffu, 0, 0);
+                        else asm volatile("" :: "v"(wv4));
+                        if constexpr (!(IRE_UP_ABL & 2))
 #pragma unroll
                         for (int d = 0; d < 4; ++d) {
                             const bf16x2_t wv = __builtin_bit_cast(bf16x2_t, inb[m] ? w[d] : 0u);     // the statistics are those of the STORED values
@@ -220,13 +228,15 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
             };
             auto unit = [&](auto u_tag) __attribute__((always_inline)) {
                 constexpr int u = decltype(u_tag)::value;
+                if constexpr (!(IRE_UP_ABL & 1)) {
                 consume(u_tag);
                 if constexpr (u + D < U) issue(std::integral_constant<int, u + D>{});
+                }
                 if constexpr ((u + 1) % (2 * NKG) == 0) finish(std::integral_constant<int, u / (2 * NKG)>{});
             };
-            issue(std::integral_constant<int, 0>{}); issue(std::integral_constant<int, 1>{});
-            issue(std::integral_constant<int, 2>{}); issue(std::integral_constant<int, 3>{});
+            if constexpr (!(IRE_UP_ABL & 1)) up_static_for<0, D>(issue);
             up_static_for<0, U>(unit);
+            if constexpr (!(IRE_UP_ABL & 2)) {
             // GroupNorm partials of the item: quad k of lane-half h is couts 16 (k >> 1) + 8 h + 4 (k & 1) .. + 3 of the block
             float rv[8] = {ssum[0], qsum[0], ssum[1], qsum[1], ssum[2], qsum[2], ssum[3], qsum[3]};
 #pragma unroll
@@ -256,6 +266,7 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
                         if (k < qpg) { sv += red[(w * 8 + tid * qpg + k) * 2 + 0]; qv += red[(w * 8 + tid * qpg + k) * 2 + 1]; }
                 float* st = a.stats + (((size_t)it.img * tiles_per_img + it.tile) * 8 + (it.nb * UP_NT) / G + tid) * 2;
                 st[0] = sv; st[1] = qv;
+            }
             }
         } else {
 #pragma unroll
@@ -342,8 +353,26 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
                     ++n;
                 }
         };
+        // fused form, levels whose skip tensor comes from HBM (C <= 64): the item's skip pixels are touched one dword per 32 B
+        // during the last stage, so that the epilogue's 16-B fragment loads find them in L2 (the epilogue is a pure
+        // load -> MFMA -> store phase: what it waits for is exactly these loads)
+        constexpr bool PREFETCH = NKS > 0 && NKS <= 4 && LAST && (IRE_UP_ABL & 8);   // measured: 325 -> 376 us at level 0 (the touches' 64 sectors per instruction cost more than they hide): off
+        unsigned pf_off = 0, pf_lim = 0, pf_dummy = 0;
+        const char* pf_base = nullptr;
+        if constexpr (PREFETCH) {
+            const int C = a.cout;
+            pf_base = reinterpret_cast<const char*>(a.in1) + (size_t)sq0.it.img * a.Hout * a.Wout * C * 2;
+            pf_off = (unsigned)((2 * (sq0.it.ty * UP_TH + wave * 2)) * a.Wout + 2 * (sq0.it.tx * UP_TW + r)) * (unsigned)(C * 2) + (unsigned)(h * 32);
+            pf_lim = (unsigned)(a.Hout * a.Wout * C * 2 - 4);
+        }
         auto group = [&](auto g_tag) __attribute__((always_inline)) {
             constexpr int g = decltype(g_tag)::value;
+            if constexpr (PREFETCH && g < 4 * NKS) {
+                constexpr int NKG = NKS / 2, pm = g / NKG, kg = g % NKG, par = pm >> 1, m = pm & 1, pa = par >> 1, pb = par & 1;
+                unsigned off = pf_off + (unsigned)(2 * m + pa) * (unsigned)(a.Wout * a.cout * 2) + (unsigned)(pb * a.cout * 2) + (unsigned)(kg * 64);
+                off = off < pf_lim ? off : pf_lim;
+                asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_dummy) : "v"(off), "s"(pf_base) : "memory");
+            }
             if constexpr (g + 1 < 18) read_group(std::integral_constant<int, g + 1>{}, afr[(g + 1) & 1], bfr[(g + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);       // keep the reads AHEAD of this group's MFMAs
             mfma_group(g_tag, afr[g & 1], bfr[g & 1]);
@@ -380,6 +409,7 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
         group(std::integral_constant<int, 15>{}); group(std::integral_constant<int, 16>{}); group(std::integral_constant<int, 17>{});
         // the stage's one wait: the s+2 reloads and the DMA'd slab of s+1 (and the previous item's output stores)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (PREFETCH) asm volatile("" :: "v"(pf_dummy));      // the touches' destination register stayed reserved until here
         if constexpr (LAST) epilogue(sq0.it);
         __syncthreads();
         sq0 = sq1; sq1 = sq2; sq2 = cursor.next();

@@ -34,7 +34,7 @@ __device__ __forceinline__ void gn_fold(const ConvArgs& a, unsigned char* smem, 
 #pragma unroll
             for (int k = 0; k < 8; ++k) { sv[k] += (double)v[k].x; qv[k] += (double)v[k].y; }
         }
-        for (int k = 0; t < a.gn_parts; t += ntl, ++k) { const float2 v = st[(size_t)t * 8]; sv[k & 7] += (double)v.x; qv[k & 7] += (double)v.y; }
+        for (; t < a.gn_parts; t += ntl) { const float2 v = st[(size_t)t * 8]; sv[0] += (double)v.x; qv[0] += (double)v.y; }
         red[tid * 2] = ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
         red[tid * 2 + 1] = ((qv[0] + qv[1]) + (qv[2] + qv[3])) + ((qv[4] + qv[5]) + (qv[6] + qv[7]));
         __syncthreads();
