@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "lib", "libire.so")
 
 # (source, extra flags).  classifier.hip carries the IEEE-exact double finalize: no FMA contraction.
 SOURCES = [
-    ("classifier.hip", ["-ffp-contract=off"]),
+    ("classifier.hip", ["-ffp-contract=off"] + (["-DCLS_ABL=" + os.environ["CLS_ABL"]] if os.environ.get("CLS_ABL") else [])),
     ("conv_mfma.hip", []),
     ("conv_rb.hip", (["-DIRE_RB_ABLATE"] if os.environ.get("IRE_RB_ABLATE") else []) +
      (["-DIRE_RB_NGP64=" + os.environ["IRE_RB_NGP64"]] if os.environ.get("IRE_RB_NGP64") else [])),

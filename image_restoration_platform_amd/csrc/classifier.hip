@@ -12,9 +12,10 @@
 // scores vs the CPU oracle).  Roofline: HBM, 3*H*W algorithmic bytes per image.
 //
 // Data layout: rgb is [N][H][W][3] u8, tightly packed.  One workgroup walks a strided set
-// of 16x64 output tiles of ONE image (blockIdx.y); each tile is staged with a 1-pixel
-// replicate-clamped halo into LDS as four u8 planes (R,G,B,grey); the horizontal blur
-// pass goes through LDS as well (libvips rounds to u8 between the two passes).
+// of 16x256 output tiles of ONE image (blockIdx.y); each tile is staged with a 1-pixel
+// replicate-clamped halo into LDS as four planes (R,G,B,grey) of PACKED u8 words, four pixels
+// per word; the horizontal blur pass goes through LDS as well (libvips rounds to u8 between
+// the two passes).  The image's last workgroup computes the scores (classifier_finalize.hpp).
 #include "classifier.hpp"
 
 #include "classifier_finalize.hpp"
@@ -23,17 +24,22 @@ namespace ire {
 
 namespace {
 
-constexpr int CT_H = 16, CT_W = 64;             // output tile
-constexpr int CH_H = CT_H + 2, CH_W = CT_W + 2; // halo tile
-constexpr int CPITCH = 68;                      // u8 plane row pitch (bytes)
+constexpr int CT_H = 16, CT_W = 256;            // output tile: 16 rows x 64 four-pixel groups
+constexpr int CG = CT_W / 4;                    // groups per tile row
+constexpr int PL_ROWS = CT_H + 2;               // halo rows -1 .. 16
+constexpr int PL_WORDS = CG + 2;                // plane row = pixels x0-4 .. x0+259 as packed u8 words: pixel x0+dx is byte 4+dx
 constexpr int NBUCKETS = 5001;
+#ifndef CLS_ABL
+#define CLS_ABL 0     // timing ablations (results wrong by design): 1 no grey tables, 2 no phase B, 4 no phase C, 8 no atomics / finalize
+#endif
+constexpr unsigned DIV44_M = 11916u;            // floor(n / 44) == (n * 11916) >> 19 for every n < 32768 (11916 * 44 = 2^19 + 16)
 
 struct ClsLds {
     unsigned int wR[256], wG[256], wB[256];
     unsigned int thr[260];
     unsigned char inv[5008];
-    unsigned char pl[4][CH_H][CPITCH];  // R, G, B, grey
-    unsigned char hb[3][CH_H][CT_W];    // horizontally blurred R,G,B for rows -1..CT_H
+    unsigned int pl[4][PL_ROWS][PL_WORDS];      // R, G, B, grey: four pixels per word
+    unsigned int hb[3][PL_ROWS][CG];            // horizontally blurred R, G, B (u8-rounded, libvips integer convsep) for rows -1 .. 16
 };
 
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
@@ -46,14 +52,38 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return v;
 }
 
+__device__ __forceinline__ unsigned cls_byte(unsigned w, int j) { return (w >> (8 * j)) & 0xffu; }
+__device__ __forceinline__ unsigned cls_pack4(unsigned a, unsigned b, unsigned c, unsigned d) { return a | (b << 8) | (c << 16) | (d << 24); }
+// sum and sum of squares of the four bytes of a word: one v_sad_u8 and one v_dot4_u32_u8
+__device__ __forceinline__ void cls_acc4(unsigned w, unsigned& s, unsigned& q) {
+    s = __builtin_amdgcn_sad_u8(w, 0u, s);
+    q = __builtin_amdgcn_udot4(w, w, q, false);
+}
+// {12, 20, 12} / 44 with libvips' integer rounding: (12 a + 20 b + 12 c + 22) / 44
+__device__ __forceinline__ unsigned cls_blur3(unsigned a, unsigned b, unsigned c) {
+    return ((12u * (a + c) + 20u * b + 22u) * DIV44_M) >> 19;
+}
+
+// One workgroup walks a strided set of 16 x 256 tiles of ONE image (blockIdx.y).  Everything between HBM and the 12 + 2
+// integer accumulators is word-wide: a thread owns a four-pixel group (three dwords of RGB bytes in, four packed u8 words
+// out: R, G, B, grey), the planes live in LDS as packed words, neighbours come from the adjacent words by byte alignment,
+// and every per-pixel quantity is packed back to bytes so that its sum and its sum of squares are one v_sad_u8 and one
+// v_dot4_u32_u8 per four pixels (a byte mask drops the pixels outside a ragged image).  The LAST workgroup of an image
+// (ticket counter) finalizes its seven scores: no second launch.
 __global__ __launch_bounds__(256) void classifier_scan_kernel(const uint8_t* __restrict__ rgb, int H, int W,
                                                               int tiles_x, int tiles_y,
                                                               const unsigned int* __restrict__ g_lin16,
                                                               const unsigned int* __restrict__ g_thr,
                                                               const unsigned char* __restrict__ g_inv,
-                                                              unsigned long long* __restrict__ sums) {
+                                                              unsigned long long* __restrict__ sums,
+                                                              unsigned long long* __restrict__ tickets,
+                                                              unsigned long long* __restrict__ parts,
+                                                              const uint8_t* __restrict__ is_jpeg,
+                                                              double* __restrict__ scores, int32_t* __restrict__ label,
+                                                              float* __restrict__ cond) {
     __shared__ ClsLds L;
     __shared__ unsigned long long red[4][CLS_NSUMS];
+    __shared__ int s_last;
     const int tid = threadIdx.x;
     const int img = blockIdx.y;
     const uint8_t* base = rgb + (size_t)img * H * W * 3;
@@ -66,7 +96,10 @@ __global__ __launch_bounds__(256) void classifier_scan_kernel(const uint8_t* __r
         L.wB[tid] = 722u * l;
         L.thr[tid] = g_thr[tid];
         if (tid == 0) L.thr[256] = g_thr[256];
-        for (int i = tid; i < NBUCKETS; i += 256) L.inv[i] = g_inv[i];
+        // 5008 bytes as 313 16-byte chunks (hipMalloc'd: aligned; the table is padded to 5008 on the host)
+        const uint4* gi = reinterpret_cast<const uint4*>(g_inv);
+        uint4* li = reinterpret_cast<uint4*>(L.inv);
+        for (int i = tid; i < 5008 / 16; i += 256) li[i] = gi[i];
     }
     __syncthreads();
 
@@ -74,67 +107,129 @@ __global__ __launch_bounds__(256) void classifier_scan_kernel(const uint8_t* __r
 #pragma unroll
     for (int i = 0; i < CLS_NSUMS; ++i) acc[i] = 0;
 
+    auto grey_of = [&](unsigned r, unsigned g, unsigned b) -> unsigned {
+        if constexpr (CLS_ABL & 1) return g;
+        const unsigned y = L.wR[r] + L.wG[g] + L.wB[b];
+        unsigned gv = L.inv[y >> 17];
+        gv += (y >= L.thr[gv + 1]) ? 1u : 0u;
+        return gv;
+    };
+
+    const int g = tid & (CG - 1), rb = tid >> 6;          // phases B, C: four-pixel group g, rows 4 rb .. 4 rb + 3
     const int ntiles = tiles_x * tiles_y;
+    // a tile's input: PL_ROWS x PL_WORDS groups of four pixels = 12 bytes = three (unaligned) dwords each, A_ITERS per thread.
+    // Groups that straddle the image's left / right edge (replicate padding) are gathered bytewise into the same form.
+    constexpr int A_ITERS = (PL_ROWS * PL_WORDS + 255) / 256;
+    unsigned pre[A_ITERS][3];
+    auto load_tile = [&](int tile) {
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int y0 = ty * CT_H, x0 = tx * CT_W;
+#pragma unroll
+        for (int k = 0; k < A_ITERS; ++k) {
+            const int i = min(tid + k * 256, PL_ROWS * PL_WORDS - 1);
+            const int py = i / PL_WORDS, wq = i - py * PL_WORDS;
+            const int gy = min(max(y0 + py - 1, 0), H - 1);
+            const int xs = x0 + 4 * (wq - 1);
+            if (xs >= 0 && xs + 3 < W) {
+                const uint8_t* p = base + ((size_t)gy * W + xs) * 3;
+                __builtin_memcpy(&pre[k][0], p, 4); __builtin_memcpy(&pre[k][1], p + 4, 4); __builtin_memcpy(&pre[k][2], p + 8, 4);
+            } else {
+                unsigned char t[12];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int gx = min(max(xs + j, 0), W - 1);
+                    const uint8_t* p = base + ((size_t)gy * W + gx) * 3;
+                    t[3 * j] = p[0]; t[3 * j + 1] = p[1]; t[3 * j + 2] = p[2];
+                }
+                pre[k][0] = cls_pack4(t[0], t[1], t[2], t[3]); pre[k][1] = cls_pack4(t[4], t[5], t[6], t[7]); pre[k][2] = cls_pack4(t[8], t[9], t[10], t[11]);
+            }
+        }
+    };
+    if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         const int y0 = ty * CT_H, x0 = tx * CT_W;
 
-        // phase A: halo tile (replicate-clamped) -> R,G,B,grey planes
-        for (int i = tid; i < CH_H * CH_W; i += 256) {
-            int py = i / CH_W, px = i - py * CH_W;
-            int gy = min(max(y0 + py - 1, 0), H - 1);
-            int gx = min(max(x0 + px - 1, 0), W - 1);
-            const uint8_t* p = base + ((size_t)gy * W + gx) * 3;
-            unsigned int r = p[0], g = p[1], b = p[2];
-            unsigned int y = L.wR[r] + L.wG[g] + L.wB[b];
-            unsigned int gv = L.inv[y >> 17];
-            gv += (y >= L.thr[gv + 1]) ? 1u : 0u;
-            L.pl[0][py][px] = (unsigned char)r;
-            L.pl[1][py][px] = (unsigned char)g;
-            L.pl[2][py][px] = (unsigned char)b;
-            L.pl[3][py][px] = (unsigned char)gv;
+        // phase A: halo tile (replicate-clamped) -> R, G, B, grey planes from the 12-byte groups prefetched into `pre` (issued a
+        // whole tile ahead: during the previous tile's phases B and C)
+#pragma unroll
+        for (int k = 0; k < A_ITERS; ++k) {
+            const int i = tid + k * 256;
+            if (i < PL_ROWS * PL_WORDS) {
+                const int py = i / PL_WORDS, wq = i - py * PL_WORDS;
+                const unsigned d0 = pre[k][0], d1 = pre[k][1], d2 = pre[k][2];          // r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3
+                const unsigned r[4] = {cls_byte(d0, 0), cls_byte(d0, 3), cls_byte(d1, 2), cls_byte(d2, 1)};
+                const unsigned gg[4] = {cls_byte(d0, 1), cls_byte(d1, 0), cls_byte(d1, 3), cls_byte(d2, 2)};
+                const unsigned b[4] = {cls_byte(d0, 2), cls_byte(d1, 1), cls_byte(d2, 0), cls_byte(d2, 3)};
+                unsigned yv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) yv[j] = grey_of(r[j], gg[j], b[j]);
+                L.pl[0][py][wq] = cls_pack4(r[0], r[1], r[2], r[3]);
+                L.pl[1][py][wq] = cls_pack4(gg[0], gg[1], gg[2], gg[3]);
+                L.pl[2][py][wq] = cls_pack4(b[0], b[1], b[2], b[3]);
+                L.pl[3][py][wq] = cls_pack4(yv[0], yv[1], yv[2], yv[3]);
+            }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);      // in flight across phases B and C
+
+        // phase B: horizontal {12,20,12}/44 pass, rounded to u8; rows 4 rb .. 4 rb + 3, and plane rows 16 + rb for rb < 2
+        if constexpr (!(CLS_ABL & 2))
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int py = k < 4 ? rb * 4 + k : CT_H + rb;
+            if (k == 4 && rb >= 2) break;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const unsigned w0 = L.pl[c][py][g], w1 = L.pl[c][py][g + 1], w2 = L.pl[c][py][g + 2];
+                const unsigned lw = (w1 << 8) | (w0 >> 24), rw = (w1 >> 8) | (w2 << 24);      // pixels x-1 .. x+2, x+1 .. x+4
+                L.hb[c][py][g] = cls_pack4(cls_blur3(cls_byte(lw, 0), cls_byte(w1, 0), cls_byte(rw, 0)), cls_blur3(cls_byte(lw, 1), cls_byte(w1, 1), cls_byte(rw, 1)),
+                                           cls_blur3(cls_byte(lw, 2), cls_byte(w1, 2), cls_byte(rw, 2)), cls_blur3(cls_byte(lw, 3), cls_byte(w1, 3), cls_byte(rw, 3)));
+            }
         }
         __syncthreads();
 
-        // phase B: horizontal {12,20,12}/44 pass, rounded to u8 (libvips integer convsep)
-        for (int i = tid; i < 3 * CH_H * CT_W; i += 256) {
-            int c = i / (CH_H * CT_W);
-            int rem = i - c * (CH_H * CT_W);
-            int py = rem / CT_W, x = rem - py * CT_W;
-            unsigned int v = 12u * L.pl[c][py][x] + 20u * L.pl[c][py][x + 1] + 12u * L.pl[c][py][x + 2];
-            L.hb[c][py][x] = (unsigned char)((v + 22u) / 44u);
-        }
-        __syncthreads();
-
-        // phase C: per-pixel accumulation, thread -> column x, rows (tid>>6) + 4k
-        {
-            const int x = tid & 63;
-            const int gx = x0 + x;
-            unsigned int s_c[3] = {0, 0, 0}, q_c[3] = {0, 0, 0};
-            unsigned int s_b = 0, q_b = 0, s8 = 0, q8 = 0, s9 = 0, q9 = 0;
-            if (gx < W) {
+        // phase C: this thread's 4 x 4 pixels
+        if constexpr (!(CLS_ABL & 4)) {
+            const int gx = x0 + 4 * g;
+            unsigned xm = 0;                                   // 0xff per pixel of the group that is inside the image
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int y = (tid >> 6) + 4 * k;
-                    if (y0 + y < H) {
-                        const int hy = y + 1, hx = x + 1;
-                        int c = L.pl[3][hy][hx];
-                        int sum9 = L.pl[3][hy - 1][hx - 1] + L.pl[3][hy - 1][hx] + L.pl[3][hy - 1][hx + 1] +
-                                   L.pl[3][hy][hx - 1] + c + L.pl[3][hy][hx + 1] +
-                                   L.pl[3][hy + 1][hx - 1] + L.pl[3][hy + 1][hx] + L.pl[3][hy + 1][hx + 1];
-                        unsigned int e8 = (unsigned int)min(max(9 * c - sum9, 0), 255);
-                        unsigned int e9 = (unsigned int)min(max(10 * c - sum9, 0), 255);
-                        s8 += e8; q8 += e8 * e8;
-                        s9 += e9; q9 += e9 * e9;
+            for (int j = 0; j < 4; ++j) xm |= (gx + j < W) ? (0xffu << (8 * j)) : 0u;
+            unsigned s_c[3] = {0, 0, 0}, q_c[3] = {0, 0, 0};
+            unsigned s_b = 0, q_b = 0, s8 = 0, q8 = 0, s9 = 0, q9 = 0;
+            // sliding window over plane rows: h3[row][j] = grey(x-1) + grey(x) + grey(x+1) of that row
+            unsigned h3[3][4], cw[3];
+            auto row_sums = [&](int py, unsigned (&h)[4], unsigned& cword) {
+                const unsigned w0 = L.pl[3][py][g], w1 = L.pl[3][py][g + 1], w2 = L.pl[3][py][g + 2];
+                const unsigned lw = (w1 << 8) | (w0 >> 24), rw = (w1 >> 8) | (w2 << 24);
 #pragma unroll
-                        for (int ch = 0; ch < 3; ++ch) {
-                            unsigned int v = L.pl[ch][hy][hx];
-                            s_c[ch] += v; q_c[ch] += v * v;
-                            unsigned int bv = 12u * L.hb[ch][hy - 1][x] + 20u * L.hb[ch][hy][x] + 12u * L.hb[ch][hy + 1][x];
-                            bv = (bv + 22u) / 44u;
-                            s_b += bv; q_b += bv * bv;
-                        }
-                    }
+                for (int j = 0; j < 4; ++j) h[j] = cls_byte(lw, j) + cls_byte(w1, j) + cls_byte(rw, j);
+                cword = w1;
+            };
+            row_sums(rb * 4, h3[0], cw[0]);
+            row_sums(rb * 4 + 1, h3[1], cw[1]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int y = rb * 4 + k, hy = y + 1;          // hy: plane row of the pixel row
+                row_sums(hy + 1, h3[(k + 2) % 3], cw[(k + 2) % 3]);
+                const unsigned m = (y0 + y < H) ? xm : 0u;
+                unsigned e8[4], e9[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = (int)cls_byte(cw[(k + 1) % 3], j);
+                    const int sum9 = (int)(h3[0][j] + h3[1][j] + h3[2][j]);
+                    e8[j] = (unsigned)min(max(9 * c - sum9, 0), 255);
+                    e9[j] = (unsigned)min(max(10 * c - sum9, 0), 255);
+                }
+                cls_acc4(cls_pack4(e8[0], e8[1], e8[2], e8[3]) & m, s8, q8);
+                cls_acc4(cls_pack4(e9[0], e9[1], e9[2], e9[3]) & m, s9, q9);
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    cls_acc4(L.pl[ch][hy][g + 1] & m, s_c[ch], q_c[ch]);
+                    const unsigned ua = L.hb[ch][hy - 1][g], ub = L.hb[ch][hy][g], uc = L.hb[ch][hy + 1][g];
+                    const unsigned bw = cls_pack4(cls_blur3(cls_byte(ua, 0), cls_byte(ub, 0), cls_byte(uc, 0)), cls_blur3(cls_byte(ua, 1), cls_byte(ub, 1), cls_byte(uc, 1)),
+                                                  cls_blur3(cls_byte(ua, 2), cls_byte(ub, 2), cls_byte(uc, 2)), cls_blur3(cls_byte(ua, 3), cls_byte(ub, 3), cls_byte(uc, 3)));
+                    cls_acc4(bw & m, s_b, q_b);
                 }
             }
             acc[0] += s_c[0]; acc[1] += s_c[1]; acc[2] += s_c[2];
@@ -143,15 +238,15 @@ __global__ __launch_bounds__(256) void classifier_scan_kernel(const uint8_t* __r
             acc[8] += s8; acc[9] += q8;
             acc[10] += s9; acc[11] += q9;
         }
-        // scratch probes: pixels on the stride-4 grid (tile origin is a multiple of 4)
-        if (tid < 64) {
-            const int y = (tid >> 4) * 4, x = (tid & 15) * 4;
+        // scratch probes: the pixels on the stride-4 grid (tile origin is a multiple of 4): one per thread
+        {
+            const unsigned char* gp = reinterpret_cast<const unsigned char*>(&L.pl[3][0][0]);
+            const int y = rb * 4, x = g * 4;
             const int gy = y0 + y, gx = x0 + x;
             if (gy < H && gx < W) {
+                auto px = [&](int yy, int xx) -> int { return gp[(yy + 1) * (PL_WORDS * 4) + 4 + xx]; };
                 auto e4 = [&](int yy, int xx) -> int {
-                    const int hy = yy + 1, hx = xx + 1;
-                    int v = 4 * L.pl[3][hy][hx] - L.pl[3][hy - 1][hx] - L.pl[3][hy + 1][hx] -
-                            L.pl[3][hy][hx - 1] - L.pl[3][hy][hx + 1];
+                    const int v = 4 * px(yy, xx) - px(yy - 1, xx) - px(yy + 1, xx) - px(yy, xx - 1) - px(yy, xx + 1);
                     return min(max(v, 0), 255);
                 };
                 if (e4(y, x) > 200) {
@@ -163,6 +258,7 @@ __global__ __launch_bounds__(256) void classifier_scan_kernel(const uint8_t* __r
         __syncthreads();  // planes are rewritten by the next tile
     }
 
+    if constexpr (CLS_ABL & 8) { if (acc[0] + acc[5] + acc[9] + acc[13] == 0x123456789ull) sums[0] = 1; return; }
     // workgroup reduction -> 14 u64 atomics per workgroup
     const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
@@ -171,29 +267,54 @@ __global__ __launch_bounds__(256) void classifier_scan_kernel(const uint8_t* __r
         if (lane == 0) red[wave][i] = v;
     }
     __syncthreads();
-    if (tid < CLS_NSUMS) {
-        unsigned long long v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-        if (v) atomicAdd(&sums[(size_t)img * CLS_NSUMS + tid], v);
+    // Workgroup partials go to this workgroup's own row of `parts` with plain stores; the image's LAST workgroup (one ticket
+    // atomic per workgroup) adds the rows -- exact integers: any order gives the same sums -- and computes the scores.  (14
+    // u64 atomics per workgroup on ONE 128-byte line per image serialise at the memory-side atomic unit: 64 workgroups x 14 =
+    // 896 per line took 31 of the kernel's 76 us.)
+    // (Device-scope atomic stores / loads, relaxed: they go to the device's coherence point without the L2 write-back and
+    // invalidate a __threadfence() costs every workgroup -- 64 workgroups per XCD queue up on those: +35 us.  The ticket is
+    // ordered after the row by waiting for the stores' acknowledgement.)
+    if (tid < CLS_NSUMS)
+        __hip_atomic_store(&parts[((size_t)img * gridDim.x + blockIdx.x) * CLS_NSUMS + tid], red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid],
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_last = __hip_atomic_fetch_add(&tickets[img], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(gridDim.x - 1);
+    __syncthreads();
+    if (!s_last) return;
+    {   // 16 row lanes x 14 columns: every thread's loads are independent (one round trip, not one per row)
+        __shared__ unsigned long long fin[CLS_NSUMS][16];
+        const int k = tid >> 4, rl = tid & 15;
+        if (k < CLS_NSUMS) {
+            unsigned long long v = 0;
+            for (unsigned b = rl; b < gridDim.x; b += 16)
+                v += __hip_atomic_load(&parts[((size_t)img * gridDim.x + b) * CLS_NSUMS + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fin[k][rl] = v;
+        }
+        __syncthreads();
+        if (tid < CLS_NSUMS) {
+            unsigned long long v = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v += fin[tid][i];
+            red[0][tid] = v;
+            sums[(size_t)img * CLS_NSUMS + tid] = v;
+        }
     }
-}
-
-__global__ void classifier_finalize_kernel(const unsigned long long* __restrict__ sums,
-                                           const uint8_t* __restrict__ is_jpeg, int n, int H, int W,
-                                           double* __restrict__ scores, int32_t* __restrict__ label,
-                                           float* __restrict__ cond) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint64_t S[CLS_NSUMS];
-    for (int k = 0; k < CLS_NSUMS; ++k) S[k] = sums[(size_t)i * CLS_NSUMS + k];
-    double sc[7];
-    int32_t lb;
-    cls_finalize_one(S, (uint64_t)H * (uint64_t)W, is_jpeg ? is_jpeg[i] : 1, sc, &lb);
-    for (int k = 0; k < 7; ++k) {
-        if (scores) scores[(size_t)i * 7 + k] = sc[k];
-        if (cond) cond[(size_t)i * 8 + k] = (float)sc[k];
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(&tickets[img], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-cleaning: the next launch starts from zero without a memset
+        uint64_t S[CLS_NSUMS];
+        for (int k = 0; k < CLS_NSUMS; ++k) S[k] = red[0][k];
+        double sc[7];
+        int32_t lb;
+        cls_finalize_one(S, (uint64_t)H * (uint64_t)W, is_jpeg ? is_jpeg[img] : 1, sc, &lb);
+        for (int k = 0; k < 7; ++k) {
+            if (scores) scores[(size_t)img * 7 + k] = sc[k];
+            if (cond) cond[(size_t)img * 8 + k] = (float)sc[k];
+        }
+        if (cond) cond[(size_t)img * 8 + 7] = 0.f;
+        if (label) label[img] = lb;
     }
-    if (cond) cond[(size_t)i * 8 + 7] = 0.f;
-    if (label) label[i] = lb;
 }
 
 __global__ void scores_to_cond_kernel(const double* __restrict__ scores, int n, float* __restrict__ cond) {
@@ -208,17 +329,17 @@ __global__ void scores_to_cond_kernel(const double* __restrict__ scores, int n, 
 void classifier_launch(const ClassifierTables& tb, const uint8_t* d_rgb, int n, int h, int w,
                        const uint8_t* d_is_jpeg, unsigned long long* d_sums, double* d_scores,
                        int32_t* d_label, float* d_cond, hipStream_t stream) {
-    IRE_HIP(hipMemsetAsync(d_sums, 0, sizeof(unsigned long long) * CLS_NSUMS * n, stream));
+    // d_sums (engine.cpp::ensure_io): [cap][14] sums | [cap] tickets (zero at allocation, reset by the kernel) | [cap][CLS_MAX_WG][14]
+    // workgroup partials -- no memset, no second launch
     const int tiles_x = ceil_div(w, CT_W), tiles_y = ceil_div(h, CT_H);
     const int ntiles = tiles_x * tiles_y;
-    // ~4 workgroups per CU chip-wide; every workgroup amortises its 9 KB table load over its tiles
-    int per_img = std::max(1, std::min(ntiles, 1024 / std::max(1, n)));
+    // three workgroups per CU chip-wide, an equal number of tiles each where the counts allow; every workgroup amortises its
+    // 9 KB table load over its tiles
+    int per_img = std::max(1, std::min(ntiles, CLS_MAX_WG / std::max(1, n)));
+    per_img = ceil_div(ntiles, ceil_div(ntiles, per_img));
     dim3 grid(per_img, n);
     hipLaunchKernelGGL(classifier_scan_kernel, grid, dim3(256), 0, stream, d_rgb, h, w, tiles_x, tiles_y,
-                       tb.lin16, tb.thr, tb.inv, d_sums);
-    IRE_HIP(hipGetLastError());
-    hipLaunchKernelGGL(classifier_finalize_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, stream, d_sums, d_is_jpeg,
-                       n, h, w, d_scores, d_label, d_cond);
+                       tb.lin16, tb.thr, tb.inv, d_sums, cls_tickets(d_sums), cls_parts(d_sums), d_is_jpeg, d_scores, d_label, d_cond);
     IRE_HIP(hipGetLastError());
 }
 

@@ -12,7 +12,16 @@ struct ClassifierTables {       // device copies of csrc/grey_tables.inc
     const unsigned char* inv;   // [IRE_GREY_NBUCKETS]
 };
 
-// Asynchronous on `stream`: zero the accumulators, scan, finalize.
+// The accumulator block of the scan (one allocation, engine.cpp::ensure_io): for a capacity of `cap` images
+//   [cap][14] u64 sums | [CLS_TICKET_CAP] u64 workgroup tickets (must be zero at allocation; the kernel resets them) | [CLS_MAX_WG][14] u64
+//   workgroup partials (a launch uses at most CLS_MAX_WG workgroups in all).
+constexpr int CLS_MAX_WG = 768;              // three workgroups per CU (42 KB of LDS, 142 VGPRs each)
+constexpr int CLS_TICKET_CAP = 64;              // >= max_batch of any engine (ire_config: 1..64)
+inline size_t cls_sums_bytes() { return ((size_t)CLS_TICKET_CAP * 14 + CLS_TICKET_CAP + (size_t)CLS_MAX_WG * 14) * 8; }
+inline unsigned long long* cls_tickets(unsigned long long* sums) { return sums + (size_t)CLS_TICKET_CAP * 14; }
+inline unsigned long long* cls_parts(unsigned long long* sums) { return sums + (size_t)CLS_TICKET_CAP * 14 + CLS_TICKET_CAP; }
+
+// Asynchronous on `stream`: ONE launch -- scan, then the image's last workgroup reduces the partials and finalizes.
 // d_scores [n][7] double, d_label [n] int32, d_cond [n][8] float (any may be null).
 void classifier_launch(const ClassifierTables& tb, const uint8_t* d_rgb, int n, int h, int w,
                        const uint8_t* d_is_jpeg, unsigned long long* d_sums, double* d_scores,

@@ -113,7 +113,8 @@ Engine::Engine(const ire_config& cfg) {
     // classifier tables
     unsigned int* d_lin = (unsigned int*)dalloc(sizeof(kLin16));
     unsigned int* d_thr = (unsigned int*)dalloc(sizeof(kGreyThr));
-    unsigned char* d_inv = (unsigned char*)dalloc(sizeof(kGreyInv));
+    unsigned char* d_inv = (unsigned char*)dalloc(5008);          // 5001 buckets, padded to whole 16-byte chunks (classifier.hip loads it as uint4)
+    IRE_HIP(hipMemset(d_inv, 0, 5008));
     table_allocs_ = {d_lin, d_thr, d_inv};
     IRE_HIP(hipMemcpy(d_lin, kLin16, sizeof(kLin16), hipMemcpyHostToDevice));
     IRE_HIP(hipMemcpy(d_thr, kGreyThr, sizeof(kGreyThr), hipMemcpyHostToDevice));
@@ -550,7 +551,8 @@ void Engine::ensure_io(int n, int h, int w) {
     d_in_ = (uint8_t*)dalloc(imgs * cap_px * 3);
     d_out_ = (uint8_t*)dalloc(imgs * cap_px * 3);
     d_jpeg_ = (uint8_t*)dalloc(imgs);
-    d_sums_ = (unsigned long long*)dalloc(imgs * 14 * 8);
+    d_sums_ = (unsigned long long*)dalloc(cls_sums_bytes());   // sums | tickets | workgroup partials (classifier.hpp)
+    IRE_HIP(hipMemset(d_sums_, 0, cls_sums_bytes()));
     d_scores_ = (double*)dalloc(imgs * 7 * 8);
     d_label_ = (int32_t*)dalloc(imgs * 4);
     d_cond_ = (float*)dalloc(imgs * 8 * 4);
