@@ -46,7 +46,7 @@ def parse_args(argv=None):
     ap.add_argument("--size", type=int, default=None, help="image side (default 1024; 2048 for --workload tiled)")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("IRE_STREAMS", "1")),
-                    help="lanes (HIP streams) per engine; 2 is ~3 %% faster but overlapping kernels would skew the per-kernel event timing")
+                    help="lanes (HIP streams) per engine; 2 is ~1 %% faster (r02: 866 -> 873 img/s) but overlapping kernels skew the per-kernel event timing the roofline is computed from")
     ap.add_argument("--workload", choices=["restore", "fusion", "classify", "tiled"], default="restore",
                     help="restore = the BASELINE metric (default); fusion = cfg 3; classify = the 7-score scan alone; tiled = cfg 4")
     ap.add_argument("--precision", choices=["bf16", "fp8"], default="bf16", help="fp8: OCP e4m3 operands for the C >= 128 ResBlock convs (cfg 4)")
