@@ -232,7 +232,7 @@ def run_restore(ctx, eng):
                 break
         ach = c3["flops"] / (c3["ms"] * 1e-3) / 1e12 if c3["ms"] > 0 else 0.0
         res["roofline"] = {
-            "kernel": "conv3x3 family: every 3x3 convolution kernel of the step (ResBlock, up, stride-2 down)", "bound": "mfma",
+            "kernel": "conv3x3 family: every 3x3 convolution kernel of the step (ResBlock convs incl. their folded GroupNorm finalize, stride-2 down, up composed with the 1x1 fuse: its flops are counted)", "bound": "mfma",
             "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
             "traffic": traffic, "traffic_source": traffic_src, "launches": c3["launches"], "avg_launch_us": 1e3 * c3["ms"] / max(1, c3["launches"]),
             "algorithmic_gflop_per_launch": c3["flops"] / max(1, c3["launches"]) / 1e9,

@@ -6,8 +6,9 @@
 `traffic`: FETCH_SIZE and WRITE_SIZE come from two separate `rocprofv3 --pmc` passes of
 `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile` (2 steps traced).  Units are KiB; on gfx950
 FETCH_SIZE reports half of the bytes of wide coalesced reads and is doubled (MI355X_MICROARCH.md, HBM / rocprofv3 section).
-The conv3x3 family = every 3x3 conv kernel the engine's profiler counts in that family (conv_rb, conv_w4, and the 3x3
-conv_mfma instantiations: TAPS == 9 with KC8 == 4, i.e. not the stem and not the 1x1 fuse).
+The conv3x3 family = every 3x3 conv kernel the engine's profiler counts in that family (conv_rb without the HEAD
+instantiation, conv_w4 / conv_f8, conv_up -- which since round 2 carries the composed 1x1 fuse -- conv_down, and the 3x3
+conv_mfma instantiations: TAPS == 9 with KC8 == 4, i.e. not the stem).
 """
 import csv
 import json
@@ -26,7 +27,9 @@ def stats(src, dst, title, footer=""):
 
 
 def is_conv3x3(name):
-    if "conv_rb_kernel" in name or "conv_w4_kernel" in name or "conv_up_kernel" in name:
+    if "conv_rb_kernel" in name:                       # the HEAD instantiation (last template argument true) is its own family
+        return not name.rstrip().endswith(", true>(ire::ConvArgs)")
+    if "conv_w4_kernel" in name or "conv_up_kernel" in name or "conv_down_kernel" in name or "conv_f8_kernel" in name:
         return True
     if "conv_mfma_kernel<4, 9," in name and not name.rstrip().endswith("true>(ire::ConvArgs)"):   # last arg = HEAD: its own family
         return True
@@ -50,7 +53,7 @@ def traffic(fetch_csv, write_csv, dst, steps):
     out = {
         "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile",
         "unit_note": "counters are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); WRITE_SIZE as is",
-        "family": "conv3x3 (conv_rb_kernel + conv_w4_kernel + conv_up_kernel, all instantiations, + the stride-2 conv_mfma_kernel instantiation)",
+        "family": "conv3x3 (conv_rb_kernel without its HEAD instantiation, conv_w4_kernel, conv_f8_kernel, conv_up_kernel, conv_down_kernel; the v1 stride-2 conv_mfma_kernel instantiation where a switch selects it)",
         "per_kernel": {},
     }
     tot_f = tot_w = 0.0
