@@ -1,0 +1,374 @@
+// conv_c32.hip -- the C = 32 convolutions of RestoreNet-v0 (8 ResBlock convs at full resolution + the 32 -> 3 head: 31 % of a
+// step) as a PRODUCER / CONSUMER workgroup: 12 waves per CU = three per SIMD, gfx950.
+//
+// Why: conv_rb.hip's C = 32 stage is instruction-issue bound with two in-order waves per SIMD (profiles/r02: the VALU pipe is
+// 62 % busy, yet the 2 x 4 700 issue cycles of the two waves add up to the measured 9 450 cycles per item: LDS, scalar and
+// matrix issue never overlap another wave's VALU).  The work of an item is two different programs -- GroupNorm+FiLM+SiLU of
+// the 18 x 34 x 32 input tile (transcendental-heavy VALU, global loads, LDS stores) and the 36 MFMAs + epilogue of a wave's
+// 2 x 32 output pixels (LDS reads, matrix issue, stores) -- so here they run as two roles on every SIMD:
+//   waves 0..7  consumers: fragments from LDS tile t & 1, 18 k-steps of 2 MFMAs, epilogue straight from the accumulators
+//                (residual, bf16 stores, GroupNorm partials -- conv_rb.hip's, unchanged);
+//   waves 8..11 producers: tile t + 1: raw bf16 rows (prefetched a whole item ahead into registers) -> y = silu(x A + B) in
+//                packed f32 -> bf16 -> LDS tile (t + 1) & 1, then the loads of tile t + 2.
+// One workgroup barrier per item.  Every wave gets 168 registers (three per SIMD); neither role needs more.  Weights (18 KB)
+// stay in LDS for the whole kernel.  Tiles, accumulation order, epilogue arithmetic and the partials layout are those of
+// conv_rb.hip's C = 32 variants: same results class (bf16 roundings identical, GroupNorm partials summed in the same order),
+// row strips included.  Roofline: HBM for the residual variant (1.5 GB per launch), VALU issue otherwise.
+#include "conv_mfma.hpp"
+#include "gn_fold.hpp"
+#include "persist.hpp"
+
+namespace ire {
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+#ifndef C3_ABL
+#define C3_ABL 0     // timing ablations (results wrong by design): 1 no transform, 2 no epilogue, 4 no MFMA loop, 8 no input loads
+#endif
+constexpr int C3_CONS = 512, C3_PROD = 256, C3_THREADS = C3_CONS + C3_PROD;
+constexpr int C3_TH = 16, C3_TW = 32, C3_IH = C3_TH + 2, C3_IW = C3_TW + 2;
+constexpr int C3_IN_CHUNKS = C3_IH * C3_IW * 4;                                 // 2448 x 16 B (32 channels per pixel)
+constexpr int C3_P_ITERS = (C3_IN_CHUNKS + C3_PROD - 1) / C3_PROD;               // 10 chunks per producer thread
+constexpr int C3_IN_BYTES = C3_P_ITERS * C3_PROD * 16;                           // 40960: every chunk slot exists
+constexpr int C3_W_CHUNKS = 18 * 2 * 32;                                        // [kk = tap*4 + c8][32 rows] x 16 B
+constexpr int C3_W_OFF = 2 * C3_IN_BYTES;
+constexpr int C3_BIAS_OFF = C3_W_OFF + C3_W_CHUNKS * 16;
+constexpr int C3_RED_OFF = C3_BIAS_OFF + 32 * 4;                                // 2 x [8 waves][4 chunks][sA, qA, sB, qB]
+constexpr int C3_RED_HALF = 8 * 4 * 4;                                          // floats
+constexpr int C3_COEF_OFF = C3_RED_OFF + 2 * C3_RED_HALF * 4;                   // (A, B) of every image this workgroup touches: [<= 64][32 ch][2] floats
+constexpr int C3_LDS = C3_COEF_OFF + 64 * 32 * 2 * 4;
+static_assert(C3_LDS <= 160 * 1024, "LDS");
+
+__device__ __forceinline__ unsigned c3_pack(float a, float b) {
+    f32x2_t f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_t));
+}
+__device__ __forceinline__ float c3_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float c3_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+template <int N> __device__ __forceinline__ float c3_ror_add(float v) {
+    const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false);
+    return v + __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ float c3_swap16_add(float v) {       // see conv_rb.hip::rb_swap16_add
+    float x = v, y = v;
+    asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return x + y;
+}
+
+// The per-item barrier.  __syncthreads() is a workgroup-scope fence + s_barrier, and the fence drains vmcnt: the producers' loads
+// of the next tile and the consumers' output stores, both issued moments before, would be waited for at every item (measured:
+// +100 us per launch).  Only LDS traffic has to be ordered here: the tile a producer just wrote, the partials a consumer just
+// wrote; global loads and stores stay in flight across the barrier.
+__device__ __forceinline__ void c3_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <bool RESID, bool HEAD>
+__global__ __launch_bounds__(C3_THREADS) void conv_c32_kernel(ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[C3_LDS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    PersistCursor cursor(a.tiles_x, a.tiles_y, a.nimg, 1, 1);      // one n-block, one stage: a stage is an item
+    const int n_items = cursor.my_items;
+    if (n_items == 0) return;
+    if (a.gn_stats) gn_fold(a, smem, cursor.first_img, cursor.last_img, 512);
+
+    {   // weights and bias stay in LDS for the whole kernel
+        const uint4* ws = reinterpret_cast<const uint4*>(a.w);
+        uint4* wd = reinterpret_cast<uint4*>(smem + C3_W_OFF);
+        for (int i = tid; i < C3_W_CHUNKS; i += C3_THREADS) wd[i] = ws[i];
+        if (tid < 32) reinterpret_cast<float*>(smem + C3_BIAS_OFF)[tid] = a.bias[tid];
+        // the GroupNorm+FiLM coefficients of the images this workgroup's items belong to (gn_fold just wrote them, or
+        // gn_finalize_kernel did): the producers read them from LDS, so that their only VMEM traffic is the input stream
+        const int nim = cursor.last_img - cursor.first_img + 1;                // <= nimg <= 64
+        const float2* ab = a.ab + (size_t)cursor.first_img * 32;
+        float2* cd = reinterpret_cast<float2*>(smem + C3_COEF_OFF);
+        for (int i = tid; i < nim * 32; i += C3_THREADS) cd[i] = ab[i];
+    }
+    __syncthreads();
+
+    if (__builtin_amdgcn_readfirstlane(wave) >= 8) {
+        // =============================== producers: waves 8..11 ===============================================================
+        const int tp = tid - C3_CONS;
+        const int c8 = tp & 3;                                   // this thread always stages the same 8-channel slice of a pixel
+        // chunk i of this thread: halo-tile pixel p = (tp + 256 i) >> 2 -- constant for the whole kernel
+        int rel[C3_P_ITERS], lds_off[C3_P_ITERS];
+        unsigned pyx[C3_P_ITERS];
+#pragma unroll
+        for (int i = 0; i < C3_P_ITERS; ++i) {
+            const int q = tp + i * C3_PROD;
+            const int p = q >> 2;
+            const int py = p / C3_IW, px = p - py * C3_IW;       // py == 18: a slot past the tile (LDS padding), never valid
+            pyx[i] = ((unsigned)py << 8) | (unsigned)px;
+            rel[i] = (py * a.Win + px) * 64 + c8 * 16;
+            lds_off[i] = (p * 4 + (c8 ^ ((p >> 2) & 3))) * 16;
+        }
+        uint4 R[C3_P_ITERS];
+        unsigned okm[C3_P_ITERS];         // all ones / zero: the chunk in R[i] lies inside the image (travels with the data)
+        float cA[8], cB[8];
+        // raw rows of item `lit`, requested chunk by chunk (load_chunk), and its image's coefficients (from LDS)
+        PersistItem lit = cursor.cur.it;
+        auto load_chunk = [&](int i) __attribute__((always_inline)) {
+            const int oy1 = lit.ty * C3_TH - 1, ox1 = lit.tx * C3_TW - 1;
+            const char* base = reinterpret_cast<const char*>(a.in0) + (size_t)lit.img * a.in_rows * a.Win * 64;
+            const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, a.in_rows * a.Win * 64, 0x00020000);
+            const int base_off = ((oy1 + a.in_row_off) * a.Win + ox1) * 64;
+            // tile-local bounds (wave-uniform): halo row py is readable iff y_lo <= py < y_hi, column px iff x_lo <= px < x_hi
+            const int y_lo = max(a.iy_lo - oy1, 0), y_hi = min(a.iy_lo + a.iy_span - oy1, C3_IH);
+            const int x_lo = max(-ox1, 0), x_hi = min(a.Win - ox1, C3_IW);
+            const int py = (int)(pyx[i] >> 8), px = (int)(pyx[i] & 0xffu);
+            const bool ok = (unsigned)(py - y_lo) < (unsigned)(y_hi - y_lo) && (unsigned)(px - x_lo) < (unsigned)(x_hi - x_lo);
+            const unsigned off = ok ? (unsigned)(base_off + rel[i]) : 0xffffffffu;       // out of range: reads as zero
+            if constexpr (C3_ABL & 8) { R[i] = make_uint4(off, 0x3f803f80u, i, 0x3f803f80u); }
+            else {
+                const u32x4_t lv = __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, 0);
+                R[i] = make_uint4(lv.x, lv.y, lv.z, lv.w);
+            }
+            okm[i] = ok ? 0xffffffffu : 0u;
+        };
+        auto load_coeffs = [&](int img) __attribute__((always_inline)) {      // (A, B) of this thread's 8 channels
+            const float4* ab = reinterpret_cast<const float4*>(smem + C3_COEF_OFF) + ((img - cursor.first_img) * 32 + c8 * 8) / 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float4 v = ab[e]; cA[2 * e] = v.x; cB[2 * e] = v.y; cA[2 * e + 1] = v.z; cB[2 * e + 1] = v.w; }
+        };
+        // Two chunks (16 channel values in 8 packed pairs) move through the transform STAGE BY STAGE (16 independent v_exp, then
+        // 16 independent v_rcp: a single in-order wave hides a transcendental's latency only behind its own independent work);
+        // as soon as a pair has been transformed the same registers are reloaded with the NEXT item's pair, so every load has
+        // most of an item's time to land and the first pair of the next transform is the oldest request.  Straight-line code on
+        // purpose: with the reloads under a branch hipcc loses the order of the pending loads at the join and waits for all.
+        auto transform_item = [&](unsigned char* tile) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < C3_P_ITERS; i += 2) {
+                const unsigned wds[8] = {R[i].x, R[i].y, R[i].z, R[i].w, R[i + 1].x, R[i + 1].y, R[i + 1].z, R[i + 1].w};
+                unsigned o[8];
+                if constexpr (C3_ABL & 1) {
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) o[w] = wds[w];
+                } else {
+                    f32x2_t y[8], e[8];
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) {
+                        // two channels at a time in packed f32: y = x A + B; silu(y) = y / (1 + 2^(-y log2 e))
+                        const int d = w & 3;
+                        const f32x2_t x = {c3_lo(wds[w]), c3_hi(wds[w])};
+                        const f32x2_t A = {cA[2 * d], cA[2 * d + 1]}, B = {cB[2 * d], cB[2 * d + 1]};
+                        y[w] = __builtin_elementwise_fma(x, A, B);
+                        e[w] = y[w] * (-1.4426950408889634f);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) e[w] = f32x2_t{__builtin_amdgcn_exp2f(e[w].x), __builtin_amdgcn_exp2f(e[w].y)};
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) e[w] = e[w] + 1.0f;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) e[w] = f32x2_t{__builtin_amdgcn_rcpf(e[w].x), __builtin_amdgcn_rcpf(e[w].y)};
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) { const f32x2_t sv = y[w] * e[w]; o[w] = c3_pack(sv.x, sv.y); }
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const unsigned m = okm[i + k];                                     // zero padding applies AFTER the activation
+                    const uint4 ov = make_uint4(o[4 * k] & m, o[4 * k + 1] & m, o[4 * k + 2] & m, o[4 * k + 3] & m);
+                    *reinterpret_cast<uint4*>(tile + lds_off[i + k]) = ov;
+                }
+                load_chunk(i); load_chunk(i + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // item 0 -> R; then every transform reloads R with the item after (past the last item the cursor stays on it: a
+        // redundant reload of rows that are never used)
+#pragma unroll
+        for (int i = 0; i < C3_P_ITERS; ++i) load_chunk(i);
+        load_coeffs(lit.img);
+        lit = cursor.next().it;
+        transform_item(smem);
+        c3_barrier();                                           // tile 0 is staged
+        for (int t = 0; t < n_items; ++t) {
+            // tile t + 1 (for t + 1 == n_items: the last item again, into the tile nobody reads any more)
+            load_coeffs(lit.img);
+            lit = cursor.next().it;
+            transform_item(smem + ((t + 1) & 1) * C3_IN_BYTES);   // the consumers finished reading this tile before the last barrier
+            c3_barrier();
+        }
+        return;
+    }
+
+    // =================================== consumers: waves 0..7 ======================================================================
+    // per-lane LDS offsets of the 18 (row m, tap) pixel fragments: p = (2 wave + m + ky) IW + r + kx, 16-B chunk index
+    // p*4 + (c8 ^ ((p >> 2) & 3)), c8 = 2 (k-step & 1) + h  (the k-step parity toggles bit 5)
+    int a_off[2][9];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int p = (wave * 2 + m + ky) * C3_IW + r + kx;
+            a_off[m][tap] = (p * 4 + (h ^ ((p >> 2) & 3))) * 16;
+        }
+    const unsigned char* wb = smem + C3_W_OFF + (h * 32 + r) * 16;         // + (tap*4 + 2 cp) * 512
+    f32x16_t bias_acc;                    // the C operand of every item's first MFMAs: the accumulators start at the bias, no moves
+    {
+        const float* bl = reinterpret_cast<const float*>(smem + C3_BIAS_OFF);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bias_acc[i] = bl[16 * (i >> 3) + 8 * h + (i & 7)];     // permuted slab rows
+    }
+    float* red_base = reinterpret_cast<float*>(smem + C3_RED_OFF);
+    int st_img = -1, st_tile = 0, st_par = 0, red_par = 0;
+    auto flush_stats = [&]() {              // partials of the item finished before the last barrier: 8 groups of 4 couts
+        if (HEAD || st_img < 0) return;
+        if (tid < 8) {
+            const float* red = red_base + st_par * C3_RED_HALF;
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const float* d = red + (w * 4 + (tid >> 1)) * 4 + 2 * (tid & 1);
+                s += d[0]; q += d[1];
+            }
+            float* st = a.stats + (((size_t)st_img * tiles_per_img + st_tile) * 8 + tid) * 2;
+            st[0] = s; st[1] = q;
+        }
+        st_img = -1;
+    };
+
+    f32x16_t acc[2];
+    uint4 erv[2][2];
+    unsigned eoffs[2];
+    bool einb[2];
+    PersistStage cs = cursor.cur;
+    c3_barrier();                                               // tile 0 is staged
+    for (int t = 0; t < n_items; ++t) {
+        const PersistItem it = cs.it;
+        const unsigned char* ib = smem + (t & 1) * C3_IN_BYTES;
+        flush_stats();
+        {   // output / residual offsets of this lane's two pixels; the residual rows are requested before the MFMAs
+            const int oyb = it.ty * C3_TH + wave * 2, ox = it.tx * C3_TW + r;
+            const bool colok = ox < a.Wout;
+            const int oxc = min(ox, a.Wout - 1);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int oy = oyb + m;
+                einb[m] = colok && oy < a.Hout;
+                eoffs[m] = ((unsigned)((min(oy, a.Hout - 1) * a.Wout + oxc) * 32) << 1) + (unsigned)(h * 16);
+            }
+            if constexpr (RESID) {
+                const char* rbase = reinterpret_cast<const char*>(a.resid) + (size_t)it.img * a.Hout * a.Wout * 64;
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) erv[g][m] = *reinterpret_cast<const uint4*>(rbase + eoffs[m] + (unsigned)(g * 32));
+            }
+        }
+        // 18 k-steps (tap, channel half): two pixel fragments + one weight fragment, read one k-step ahead of its MFMAs
+        bf16x8_t af[2][2], bf[2];
+        auto read_k = [&](int g, bf16x8_t (&pa)[2], bf16x8_t& pw) __attribute__((always_inline)) {
+            const int tap = g >> 1, cp = g & 1;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) pa[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ib + (a_off[m][tap] ^ (cp << 5))));
+            pw = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wb + (tap * 4 + 2 * cp) * 512));
+        };
+        read_k(0, af[0], bf[0]);
+        if constexpr (!(C3_ABL & 4))
+#pragma unroll
+        for (int g = 0; g < 18; ++g) {
+            if (g + 1 < 18) read_k(g + 1, af[(g + 1) & 1], bf[(g + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[g & 1], af[g & 1][m], g == 0 ? bias_acc : acc[m], 0, 0, 0);   // D[cout][pixel]
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- epilogue (conv_rb.hip's): accumulator i of lane (r, h) is cout 16 (i >> 3) + 8 h + (i & 7) ------------------------
+        if constexpr (HEAD) {
+            const int ox = it.tx * C3_TW + r;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int oy = it.ty * C3_TH + wave * 2 + m;
+                if (h == 0 && oy < a.Hout && ox < a.Wout) {
+                    const size_t gpx = (((size_t)it.img * a.Hout + oy) * a.Wout + ox) * 3;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        float vv = (float)a.u8_in[gpx + c] + acc[m][c];          // the bias is already in the accumulator
+                        vv = fminf(fmaxf(vv, 0.f), 255.f);
+                        a.u8_out[gpx + c] = (unsigned char)(int)floorf(vv + 0.5f);
+                    }
+                }
+            }
+        } else if constexpr (C3_ABL & 2) {
+            if (acc[0][0] + acc[1][5] == 1.2345f) a.out[0] = 1;
+        } else {
+            char* obase = reinterpret_cast<char*>(a.out) + (size_t)it.img * a.Hout * a.Wout * 64;
+            const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.Hout * a.Wout * 64, 0x00020000);
+            const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+            float* redw = red_base + red_par * C3_RED_HALF;
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                float sA = 0.f, qA = 0.f, sB = 0.f, qB = 0.f;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const f32x16_t& c = acc[m];
+                    unsigned w[4] = {c3_pack(c[8 * pp + 0], c[8 * pp + 1]), c3_pack(c[8 * pp + 2], c[8 * pp + 3]),
+                                     c3_pack(c[8 * pp + 4], c[8 * pp + 5]), c3_pack(c[8 * pp + 6], c[8 * pp + 7])};
+                    if constexpr (RESID) {
+                        const uint4 rr = erv[pp][m];
+                        const unsigned rw[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) w[d] = c3_pack(c3_lo(w[d]) + c3_lo(rw[d]), c3_hi(w[d]) + c3_hi(rw[d]));
+                    }
+                    float ts0 = 0.f, tq0 = 0.f, ts1 = 0.f, tq1 = 0.f;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const bf16x2_t wv = __builtin_bit_cast(bf16x2_t, w[d]);
+                        if (d < 2) { ts0 = __builtin_amdgcn_fdot2_f32_bf16(wv, ones, ts0, false); tq0 = __builtin_amdgcn_fdot2_f32_bf16(wv, wv, tq0, false); }
+                        else { ts1 = __builtin_amdgcn_fdot2_f32_bf16(wv, ones, ts1, false); tq1 = __builtin_amdgcn_fdot2_f32_bf16(wv, wv, tq1, false); }
+                    }
+                    sA += einb[m] ? ts0 : 0.f; qA += einb[m] ? tq0 : 0.f; sB += einb[m] ? ts1 : 0.f; qB += einb[m] ? tq1 : 0.f;
+                    const u32x4_t wv4 = {w[0], w[1], w[2], w[3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(wv4, orsrc, einb[m] ? eoffs[m] + (unsigned)(pp * 32) : 0xffffffffu, 0, 0);
+                }
+                // sums over the 32 lanes of each half (= one 16-B chunk of the pixel each), four chains side by side
+                sA = c3_ror_add<1>(sA); qA = c3_ror_add<1>(qA); sB = c3_ror_add<1>(sB); qB = c3_ror_add<1>(qB);
+                sA = c3_ror_add<2>(sA); qA = c3_ror_add<2>(qA); sB = c3_ror_add<2>(sB); qB = c3_ror_add<2>(qB);
+                sA = c3_ror_add<4>(sA); qA = c3_ror_add<4>(qA); sB = c3_ror_add<4>(sB); qB = c3_ror_add<4>(qB);
+                sA = c3_ror_add<8>(sA); qA = c3_ror_add<8>(qA); sB = c3_ror_add<8>(sB); qB = c3_ror_add<8>(qB);
+                sA = c3_swap16_add(sA); qA = c3_swap16_add(qA); sB = c3_swap16_add(sB); qB = c3_swap16_add(qB);
+                if ((lane & 31) == 0) {
+                    float* d = redw + (wave * 4 + 2 * pp + h) * 4;
+                    d[0] = sA; d[1] = qA; d[2] = sB; d[3] = qB;
+                }
+            }
+            st_img = it.img; st_tile = it.tile; st_par = red_par; red_par ^= 1;
+        }
+        cs = cursor.next();
+        c3_barrier();
+    }
+    flush_stats();
+}
+
+}  // namespace
+
+// C = 32 ResBlock convs with the activation applied while staging (a.ab required), and the head: a.w = permuted-row slab
+// [kk = tap*4 + c8][32][8] (engine.cpp::make_conv d_wp), 16x32 tiles, a.stats = partials [img][tile][8][2] (not for the head)
+void conv_c32_launch(bool resid, bool head, const ConvArgs& a, hipStream_t stream) {
+    if (a.cout != 32 || a.cin0 != 32 || a.nkc != 1 || a.nblocks != 1 || !a.ab) fail(IRE_ERR_INTERNAL, "internal: conv_c32 arguments");
+    if (head ? (!a.u8_in || !a.u8_out) : !a.stats) fail(IRE_ERR_INTERNAL, "internal: conv_c32 arguments");
+    const int items = a.tiles_x * a.tiles_y * a.nimg;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int grid = items < cus ? items : cus;
+    if (head) hipLaunchKernelGGL((conv_c32_kernel<false, true>), dim3(grid), dim3(C3_THREADS), 0, stream, a);
+    else if (resid) hipLaunchKernelGGL((conv_c32_kernel<true, false>), dim3(grid), dim3(C3_THREADS), 0, stream, a);
+    else hipLaunchKernelGGL((conv_c32_kernel<false, false>), dim3(grid), dim3(C3_THREADS), 0, stream, a);
+    IRE_HIP(hipGetLastError());
+}
+
+}  // namespace ire

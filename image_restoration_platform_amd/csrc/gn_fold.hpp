@@ -13,9 +13,11 @@
 
 namespace ire {
 
-// smem: >= blockDim.x * 16 + 64 bytes of LDS not otherwise in use yet; ends with a barrier, the coefficient stores retired.
-__device__ __forceinline__ void gn_fold(const ConvArgs& a, unsigned char* smem, int img_lo, int img_hi) {
-    const int tid = threadIdx.x, nthr = blockDim.x;
+// smem: >= nthr * 16 + 64 bytes of LDS not otherwise in use yet; ends with a barrier, the coefficient stores retired.
+// nthr_used: the threads that take part (a power of two <= blockDim.x; 0 = all of them): the rest only join the barriers.
+__device__ __forceinline__ void gn_fold(const ConvArgs& a, unsigned char* smem, int img_lo, int img_hi, int nthr_used = 0) {
+    const int tid = threadIdx.x, nthr = nthr_used ? nthr_used : (int)blockDim.x;
+    const bool act = tid < nthr;
     double* red = reinterpret_cast<double*>(smem);                       // [nthr][2]
     float* mr = reinterpret_cast<float*>(smem + (size_t)nthr * 16);      // [8][2] mean, rstd
     const int g = tid & 7, tl = tid >> 3, ntl = nthr >> 3;               // thread = (tile lane, group): a tile's 8 groups are 64 contiguous bytes
@@ -26,7 +28,7 @@ __device__ __forceinline__ void gn_fold(const ConvArgs& a, unsigned char* smem, 
         double sv[8], qv[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) { sv[k] = 0.0; qv[k] = 0.0; }
-        int t = tl;
+        int t = act ? tl : a.gn_parts;
         for (; t + 7 * ntl < a.gn_parts; t += 8 * ntl) {
             float2 v[8];
 #pragma unroll
@@ -35,11 +37,13 @@ __device__ __forceinline__ void gn_fold(const ConvArgs& a, unsigned char* smem, 
             for (int k = 0; k < 8; ++k) { sv[k] += (double)v[k].x; qv[k] += (double)v[k].y; }
         }
         for (; t < a.gn_parts; t += ntl) { const float2 v = st[(size_t)t * 8]; sv[0] += (double)v.x; qv[0] += (double)v.y; }
-        red[tid * 2] = ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
-        red[tid * 2 + 1] = ((qv[0] + qv[1]) + (qv[2] + qv[3])) + ((qv[4] + qv[5]) + (qv[6] + qv[7]));
+        if (act) {
+            red[tid * 2] = ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
+            red[tid * 2 + 1] = ((qv[0] + qv[1]) + (qv[2] + qv[3])) + ((qv[4] + qv[5]) + (qv[6] + qv[7]));
+        }
         __syncthreads();
         for (int off = ntl >> 1; off >= 1; off >>= 1) {
-            if (tl < off) { red[tid * 2] += red[(tid + off * 8) * 2]; red[tid * 2 + 1] += red[(tid + off * 8) * 2 + 1]; }
+            if (act && tl < off) { red[tid * 2] += red[(tid + off * 8) * 2]; red[tid * 2 + 1] += red[(tid + off * 8) * 2 + 1]; }
             __syncthreads();
         }
         if (tid < 8) {
@@ -51,7 +55,7 @@ __device__ __forceinline__ void gn_fold(const ConvArgs& a, unsigned char* smem, 
             mr[tid * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
         }
         __syncthreads();
-        for (int c = tid; c < C; c += nthr) {
+        for (int c = act ? tid : C; c < C; c += nthr) {
             const int gg = c / G;
             const float rg = mr[gg * 2 + 1] * a.gn_gamma[c];
             float sc = 0.f, sh = 0.f;
