@@ -18,6 +18,8 @@
 #include "gn_fold.hpp"
 #include "persist.hpp"
 
+#include <type_traits>
+
 namespace ire {
 
 namespace {
@@ -309,6 +311,9 @@ __global__ __launch_bounds__(C3_THREADS) void conv_c32_kernel(ConvArgs a) {
             const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.Hout * a.Wout * 64, 0x00020000);
             const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
             float* redw = red_base + red_par * C3_RED_HALF;
+            const float mf[2] = {einb[0] ? 1.f : 0.f, einb[1] ? 1.f : 0.f};      // a pixel outside the image counts for nothing
+            // v[2 pp + e] = (sum, sum of squares) of this lane's couts 16 pp + 8 h + 4 e .. + 3 over its two pixels
+            float vs[4], vq[4];
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp) {
                 float sA = 0.f, qA = 0.f, sB = 0.f, qB = 0.f;
@@ -330,19 +335,33 @@ __global__ __launch_bounds__(C3_THREADS) void conv_c32_kernel(ConvArgs a) {
                         if (d < 2) { ts0 = __builtin_amdgcn_fdot2_f32_bf16(wv, ones, ts0, false); tq0 = __builtin_amdgcn_fdot2_f32_bf16(wv, wv, tq0, false); }
                         else { ts1 = __builtin_amdgcn_fdot2_f32_bf16(wv, ones, ts1, false); tq1 = __builtin_amdgcn_fdot2_f32_bf16(wv, wv, tq1, false); }
                     }
-                    sA += einb[m] ? ts0 : 0.f; qA += einb[m] ? tq0 : 0.f; sB += einb[m] ? ts1 : 0.f; qB += einb[m] ? tq1 : 0.f;
+                    sA = __builtin_fmaf(ts0, mf[m], sA); qA = __builtin_fmaf(tq0, mf[m], qA); sB = __builtin_fmaf(ts1, mf[m], sB); qB = __builtin_fmaf(tq1, mf[m], qB);
                     const u32x4_t wv4 = {w[0], w[1], w[2], w[3]};
                     __builtin_amdgcn_raw_buffer_store_b128(wv4, orsrc, einb[m] ? eoffs[m] + (unsigned)(pp * 32) : 0xffffffffu, 0, 0);
                 }
-                // sums over the 32 lanes of each half (= one 16-B chunk of the pixel each), four chains side by side
-                sA = c3_ror_add<1>(sA); qA = c3_ror_add<1>(qA); sB = c3_ror_add<1>(sB); qB = c3_ror_add<1>(qB);
-                sA = c3_ror_add<2>(sA); qA = c3_ror_add<2>(qA); sB = c3_ror_add<2>(sB); qB = c3_ror_add<2>(qB);
-                sA = c3_ror_add<4>(sA); qA = c3_ror_add<4>(qA); sB = c3_ror_add<4>(sB); qB = c3_ror_add<4>(qB);
-                sA = c3_ror_add<8>(sA); qA = c3_ror_add<8>(qA); sB = c3_ror_add<8>(sB); qB = c3_ror_add<8>(qB);
-                sA = c3_swap16_add(sA); qA = c3_swap16_add(qA); sB = c3_swap16_add(sB); qB = c3_swap16_add(qB);
-                if ((lane & 31) == 0) {
-                    float* d = redw + (wave * 4 + 2 * pp + h) * 4;
-                    d[0] = sA; d[1] = qA; d[2] = sB; d[3] = qB;
+                vs[2 * pp] = sA; vq[2 * pp] = qA; vs[2 * pp + 1] = sB; vq[2 * pp + 1] = qB;
+            }
+            // Sum of each of the 8 values over the 32 lanes of a half, TRANSPOSING for the first two steps: a lane keeps half of
+            // its values and hands the other half to its partner (lane ^ 1, then lane ^ 2), so 8 -> 4 -> 2 values per lane; those two
+            // take the plain steps over lane bits 2, 3 and 4.  28 instead of 56 cross-lane instructions; fixed order.  Lane l of a
+            // half ends with (kind = b0: sum / sum of squares) of the quads 2 b1 and 2 b1 + 1, i.e. of chunk pp = b1.
+            {
+                const bool b0 = lane & 1, b1 = lane & 2;
+                auto xch = [&](float keep, float give, auto ctrl_tag) __attribute__((always_inline)) -> float {
+                    const int g = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), decltype(ctrl_tag)::value, 0xf, 0xf, false);
+                    return keep + __builtin_bit_cast(float, g);
+                };
+                float u[4], t2[2];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) u[k] = xch(b0 ? vq[k] : vs[k], b0 ? vs[k] : vq[k], std::integral_constant<int, 0xb1>{});     // quad_perm [1,0,3,2]: lane ^ 1
+#pragma unroll
+                for (int k = 0; k < 2; ++k) t2[k] = xch(b1 ? u[2 + k] : u[k], b1 ? u[k] : u[2 + k], std::integral_constant<int, 0x4e>{});   // quad_perm [2,3,0,1]: lane ^ 2
+                t2[0] = c3_ror_add<4>(t2[0]); t2[1] = c3_ror_add<4>(t2[1]);
+                t2[0] = c3_ror_add<8>(t2[0]); t2[1] = c3_ror_add<8>(t2[1]);
+                t2[0] = c3_swap16_add(t2[0]); t2[1] = c3_swap16_add(t2[1]);
+                if ((lane & 28) == 0) {
+                    float* d = redw + (wave * 4 + (b1 ? 2 : 0) + h) * 4 + (b0 ? 1 : 0);
+                    d[0] = t2[0]; d[2] = t2[1];
                 }
             }
             st_img = it.img; st_tile = it.tile; st_par = red_par; red_par ^= 1;
