@@ -44,7 +44,8 @@ constexpr int C3_BIAS_OFF = C3_W_OFF + C3_W_CHUNKS * 16;
 constexpr int C3_RED_OFF = C3_BIAS_OFF + 32 * 4;                                // 2 x [8 waves][4 chunks][sA, qA, sB, qB]
 constexpr int C3_RED_HALF = 8 * 4 * 4;                                          // floats
 constexpr int C3_COEF_OFF = C3_RED_OFF + 2 * C3_RED_HALF * 4;                   // (A, B) of every image this workgroup touches: [<= 64][32 ch][2] floats
-constexpr int C3_LDS = C3_COEF_OFF + 64 * 32 * 2 * 4;
+constexpr int C3_HEAD_OFF = C3_COEF_OFF + 64 * 32 * 2 * 4;                      // head: [8 waves][in | out][2 rows][96 B] RGB bytes of a wave's pixels
+constexpr int C3_LDS = C3_HEAD_OFF + 8 * 2 * 2 * 96;
 static_assert(C3_LDS <= 160 * 1024, "LDS");
 
 __device__ __forceinline__ unsigned c3_pack(float a, float b) {
@@ -246,6 +247,9 @@ __global__ __launch_bounds__(C3_THREADS) void conv_c32_kernel(ConvArgs a) {
     uint4 erv[2][2];
     unsigned eoffs[2];
     bool einb[2];
+    unsigned hin[2] = {0u, 0u};           // head: this lane's dword of the two image rows
+    size_t hoff[2] = {0, 0};
+    bool hok[2] = {false, false};
     PersistStage cs = cursor.cur;
     c3_barrier();                                               // tile 0 is staged
     for (int t = 0; t < n_items; ++t) {
@@ -269,6 +273,18 @@ __global__ __launch_bounds__(C3_THREADS) void conv_c32_kernel(ConvArgs a) {
 #pragma unroll
                     for (int m = 0; m < 2; ++m) erv[g][m] = *reinterpret_cast<const uint4*>(rbase + eoffs[m] + (unsigned)(g * 32));
             }
+            if constexpr (HEAD) {
+                // the wave's two rows of the ORIGINAL image, 32 pixels = 96 contiguous bytes each: 24 dwords per row, requested
+                // before the MFMAs (a row starts dword-aligned: W is a multiple of 8 and the tile column of 32)
+                const int vbytes = 3 * min(C3_TW, a.Wout - it.tx * C3_TW);          // a multiple of 24
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int oy = oyb + m;
+                    hok[m] = oy < a.Hout && 4 * lane < vbytes;
+                    hoff[m] = (((size_t)it.img * a.Hout + min(oy, a.Hout - 1)) * a.Wout + it.tx * C3_TW) * 3 + 4 * (size_t)min(lane, 23);
+                    hin[m] = hok[m] ? *reinterpret_cast<const unsigned*>(a.u8_in + hoff[m]) : 0u;
+                }
+            }
         }
         // 18 k-steps (tap, channel half): two pixel fragments + one weight fragment, read one k-step ahead of its MFMAs
         bf16x8_t af[2][2], bf[2];
@@ -290,20 +306,26 @@ __global__ __launch_bounds__(C3_THREADS) void conv_c32_kernel(ConvArgs a) {
         }
         // ---- epilogue (conv_rb.hip's): accumulator i of lane (r, h) is cout 16 (i >> 3) + 8 h + (i & 7) ------------------------
         if constexpr (HEAD) {
-            const int ox = it.tx * C3_TW + r;
+            // out = clamp(round(in + y)) for the 3 channels: the image bytes travel as dwords (one load and one store instruction
+            // per row instead of three byte-wide ones each) and are re-sliced per pixel through a 192-byte wave-private LDS patch
+            unsigned char* hp = smem + C3_HEAD_OFF + wave * (2 * 2 * 96);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                if (lane < 24) *reinterpret_cast<unsigned*>(hp + m * 96 + 4 * lane) = hin[m];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                const int oy = it.ty * C3_TH + wave * 2 + m;
-                if (h == 0 && oy < a.Hout && ox < a.Wout) {
-                    const size_t gpx = (((size_t)it.img * a.Hout + oy) * a.Wout + ox) * 3;
+                if (h == 0) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        float vv = (float)a.u8_in[gpx + c] + acc[m][c];          // the bias is already in the accumulator
+                        float vv = (float)hp[m * 96 + 3 * r + c] + acc[m][c];          // the bias is already in the accumulator
                         vv = fminf(fmaxf(vv, 0.f), 255.f);
-                        a.u8_out[gpx + c] = (unsigned char)(int)floorf(vv + 0.5f);
+                        hp[192 + m * 96 + 3 * r + c] = (unsigned char)(int)floorf(vv + 0.5f);
                     }
                 }
             }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                if (hok[m]) *reinterpret_cast<unsigned*>(a.u8_out + hoff[m]) = *reinterpret_cast<const unsigned*>(hp + 192 + m * 96 + 4 * min(lane, 23));
         } else if constexpr (C3_ABL & 2) {
             if (acc[0][0] + acc[1][5] == 1.2345f) a.out[0] = 1;
         } else {
