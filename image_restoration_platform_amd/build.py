@@ -25,7 +25,7 @@ SOURCES = [
      (["-DIRE_UP_D=" + os.environ["IRE_UP_D"]] if os.environ.get("IRE_UP_D") else [])),
     ("conv_down.hip", []),
     ("conv_f8.hip", []),
-    ("conv_c32.hip", (["-DC3_ABL=" + os.environ["C3_ABL"]] if os.environ.get("C3_ABL") else [])),
+    ("conv_pc.hip", (["-DC3_ABL=" + os.environ["C3_ABL"]] if os.environ.get("C3_ABL") else [])),
     ("gn.hip", []),
     ("fusion.hip", []),
     ("preprocess.hip", []),

@@ -80,9 +80,9 @@ void conv_f8_launch(bool resid, const ConvArgs& a, hipStream_t stream);
 void conv_down_launch(const ConvArgs& a, hipStream_t stream);
 // CONV_HEAD through the pipelined kernel (conv_rb.hip, HEAD variant): a.w = permuted-row slab (32 rows, 3 used), 16x32 tiles.
 void conv_head_launch(const ConvArgs& a, hipStream_t stream);
-// C = 32 ResBlock convs (fused activation) and the head as a producer / consumer workgroup, three waves per SIMD (conv_c32.hip):
-// a.w = permuted-row slab (32 rows), 16x32 tiles, partials layout of conv_rb_launch.
-void conv_c32_launch(bool resid, bool head, const ConvArgs& a, hipStream_t stream);
+// C = 32 / 64 ResBlock convs (fused activation) and the head as a producer / consumer workgroup, three waves per SIMD
+// (conv_pc.hip): a.w = permuted-row slab (C rows), 16x32 tiles, partials layout of conv_rb_launch; C = 64: a.nimg <= 8.
+void conv_pc_launch(bool resid, bool head, const ConvArgs& a, hipStream_t stream);
 // CONV_UP as a sub-pixel convolution on the low-resolution grid (conv_up.hip): 4 output parities x 2x2 pre-summed taps.
 // a.Hin/Win = low-res source, a.Hout/Wout = 2x; a.nkc = Cin/32 (even), a.nblocks = cout/32, tiles of 16x32 LOW-res pixels.
 void conv_up_subpixel_launch(const ConvArgs& a, hipStream_t stream);

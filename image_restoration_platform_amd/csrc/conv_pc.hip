@@ -1,4 +1,4 @@
-// conv_c32.hip -- the C = 32 convolutions of RestoreNet-v0 (8 ResBlock convs at full resolution + the 32 -> 3 head: 31 % of a
+// conv_pc.hip -- the C = 32 and C = 64 ResBlock convolutions of RestoreNet-v0 and the 32 -> 3 head (17 launches, half of a
 // step) as a PRODUCER / CONSUMER workgroup: 12 waves per CU = three per SIMD, gfx950.
 //
 // Why: conv_rb.hip's C = 32 stage is instruction-issue bound with two in-order waves per SIMD (profiles/r02: the VALU pipe is
@@ -10,8 +10,9 @@
 //                (residual, bf16 stores, GroupNorm partials -- conv_rb.hip's, unchanged);
 //   waves 8..11 producers: tile t + 1: raw bf16 rows (prefetched a whole item ahead into registers) -> y = silu(x A + B) in
 //                packed f32 -> bf16 -> LDS tile (t + 1) & 1, then the loads of tile t + 2.
-// One workgroup barrier per item.  Every wave gets 168 registers (three per SIMD); neither role needs more.  Weights (18 KB)
-// stay in LDS for the whole kernel.  Tiles, accumulation order, epilogue arithmetic and the partials layout are those of
+// One workgroup barrier per 32-channel stage (C = 32: one stage per item; C = 64: two, 64 couts per item = two n-tiles per
+// wave).  Every wave gets 168 registers (three per SIMD); neither role needs more.  Weights (18 / 72 KB) stay in LDS for the
+// whole kernel.  Tiles, accumulation order, epilogue arithmetic and the partials layout are those of
 // conv_rb.hip's C = 32 variants: same results class (bf16 roundings identical, GroupNorm partials summed in the same order),
 // row strips included.  Roofline: HBM for the residual variant (1.5 GB per launch), VALU issue otherwise.
 #include "conv_mfma.hpp"
@@ -35,18 +36,25 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #endif
 constexpr int C3_CONS = 512, C3_PROD = 256, C3_THREADS = C3_CONS + C3_PROD;
 constexpr int C3_TH = 16, C3_TW = 32, C3_IH = C3_TH + 2, C3_IW = C3_TW + 2;
-constexpr int C3_IN_CHUNKS = C3_IH * C3_IW * 4;                                 // 2448 x 16 B (32 channels per pixel)
-constexpr int C3_P_ITERS = (C3_IN_CHUNKS + C3_PROD - 1) / C3_PROD;               // 10 chunks per producer thread
+constexpr int C3_IN_CHUNKS = C3_IH * C3_IW * 4;                                 // 2448 x 16 B (32 channels per pixel and stage)
+constexpr int C3_P_ITERS = (C3_IN_CHUNKS + C3_PROD - 1) / C3_PROD;               // 10 chunks per producer thread and stage
 constexpr int C3_IN_BYTES = C3_P_ITERS * C3_PROD * 16;                           // 40960: every chunk slot exists
-constexpr int C3_W_CHUNKS = 18 * 2 * 32;                                        // [kk = tap*4 + c8][32 rows] x 16 B
-constexpr int C3_W_OFF = 2 * C3_IN_BYTES;
-constexpr int C3_BIAS_OFF = C3_W_OFF + C3_W_CHUNKS * 16;
-constexpr int C3_RED_OFF = C3_BIAS_OFF + 32 * 4;                                // 2 x [8 waves][4 chunks][sA, qA, sB, qB]
-constexpr int C3_RED_HALF = 8 * 4 * 4;                                          // floats
-constexpr int C3_COEF_OFF = C3_RED_OFF + 2 * C3_RED_HALF * 4;                   // (A, B) of every image this workgroup touches: [<= 64][32 ch][2] floats
-constexpr int C3_HEAD_OFF = C3_COEF_OFF + 64 * 32 * 2 * 4;                      // head: [8 waves][in | out][2 rows][96 B] RGB bytes of a wave's pixels
-constexpr int C3_LDS = C3_HEAD_OFF + 8 * 2 * 2 * 96;
-static_assert(C3_LDS <= 160 * 1024, "LDS");
+template <int C> struct PcCfg {
+    static constexpr int NKC = C / 32;                                          // 32-channel stages per item
+    static constexpr int NTL = C / 32;                                          // 32-cout n-tiles per wave
+    static constexpr int W_STAGE = 36 * C * 16;                                 // [kk = tap*4 + c8][C rows] x 16 B per stage
+    static constexpr int W_CHUNKS = NKC * 36 * C;
+    static constexpr int W_OFF = 2 * C3_IN_BYTES;
+    static constexpr int BIAS_OFF = W_OFF + W_CHUNKS * 16;
+    static constexpr int NCC = C / 8;                                           // 16-B chunks of an output pixel
+    static constexpr int RED_OFF = BIAS_OFF + C * 4;                            // 2 x [8 waves][NCC chunks][sA, qA, sB, qB]
+    static constexpr int RED_HALF = 8 * NCC * 4;                                // floats
+    static constexpr int COEF_IMGS = C == 32 ? 64 : 8;                          // images whose (A, B) the LDS table holds
+    static constexpr int COEF_OFF = RED_OFF + 2 * RED_HALF * 4;
+    static constexpr int HEAD_OFF = COEF_OFF + COEF_IMGS * C * 2 * 4;           // head: [8 waves][in | out][2 rows][96 B]
+    static constexpr int LDS = HEAD_OFF + (C == 32 ? 8 * 2 * 2 * 96 : 0);
+    static_assert(LDS <= 160 * 1024, "LDS");
+};
 
 __device__ __forceinline__ unsigned c3_pack(float a, float b) {
     f32x2_t f = {a, b};
@@ -70,30 +78,34 @@ __device__ __forceinline__ float c3_swap16_add(float v) {       // see conv_rb.h
 // wrote; global loads and stores stay in flight across the barrier.
 __device__ __forceinline__ void c3_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool RESID, bool HEAD>
-__global__ __launch_bounds__(C3_THREADS) void conv_c32_kernel(ConvArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[C3_LDS];
+template <int C, bool RESID, bool HEAD>
+__global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
+    using K = PcCfg<C>;
+    constexpr int NKC = K::NKC, NTL = K::NTL, NCC = K::NCC;
+    static_assert(!HEAD || C == 32, "the head is a C = 32 layer");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[K::LDS];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
     const int tiles_per_img = a.tiles_x * a.tiles_y;
-    PersistCursor cursor(a.tiles_x, a.tiles_y, a.nimg, 1, 1);      // one n-block, one stage: a stage is an item
+    PersistCursor cursor(a.tiles_x, a.tiles_y, a.nimg, 1, NKC);    // one n-block; a cursor step is one 32-channel stage
     const int n_items = cursor.my_items;
     if (n_items == 0) return;
+    const int n_stages = n_items * NKC;
     if (a.gn_stats) gn_fold(a, smem, cursor.first_img, cursor.last_img, 512);
 
     {   // weights and bias stay in LDS for the whole kernel
         const uint4* ws = reinterpret_cast<const uint4*>(a.w);
-        uint4* wd = reinterpret_cast<uint4*>(smem + C3_W_OFF);
-        for (int i = tid; i < C3_W_CHUNKS; i += C3_THREADS) wd[i] = ws[i];
-        if (tid < 32) reinterpret_cast<float*>(smem + C3_BIAS_OFF)[tid] = a.bias[tid];
+        uint4* wd = reinterpret_cast<uint4*>(smem + K::W_OFF);
+        for (int i = tid; i < K::W_CHUNKS; i += C3_THREADS) wd[i] = ws[i];
+        if (tid < C) reinterpret_cast<float*>(smem + K::BIAS_OFF)[tid] = a.bias[tid];
         // the GroupNorm+FiLM coefficients of the images this workgroup's items belong to (gn_fold just wrote them, or
         // gn_finalize_kernel did): the producers read them from LDS, so that their only VMEM traffic is the input stream
-        const int nim = cursor.last_img - cursor.first_img + 1;                // <= nimg <= 64
-        const float2* ab = a.ab + (size_t)cursor.first_img * 32;
-        float2* cd = reinterpret_cast<float2*>(smem + C3_COEF_OFF);
-        for (int i = tid; i < nim * 32; i += C3_THREADS) cd[i] = ab[i];
+        const int nim = cursor.last_img - cursor.first_img + 1;                // <= COEF_IMGS (conv_pc_launch checks nimg)
+        const float2* ab = a.ab + (size_t)cursor.first_img * C;
+        float2* cd = reinterpret_cast<float2*>(smem + K::COEF_OFF);
+        for (int i = tid; i < nim * C; i += C3_THREADS) cd[i] = ab[i];
     }
     __syncthreads();
 
@@ -110,19 +122,20 @@ __global__ __launch_bounds__(C3_THREADS) void conv_c32_kernel(ConvArgs a) {
             const int p = q >> 2;
             const int py = p / C3_IW, px = p - py * C3_IW;       // py == 18: a slot past the tile (LDS padding), never valid
             pyx[i] = ((unsigned)py << 8) | (unsigned)px;
-            rel[i] = (py * a.Win + px) * 64 + c8 * 16;
+            rel[i] = (py * a.Win + px) * (2 * C) + c8 * 16;
             lds_off[i] = (p * 4 + (c8 ^ ((p >> 2) & 3))) * 16;
         }
         uint4 R[C3_P_ITERS];
         unsigned okm[C3_P_ITERS];         // all ones / zero: the chunk in R[i] lies inside the image (travels with the data)
         float cA[8], cB[8];
-        // raw rows of item `lit`, requested chunk by chunk (load_chunk), and its image's coefficients (from LDS)
-        PersistItem lit = cursor.cur.it;
+        // raw rows of stage `ls` (item, 32-channel slice), requested chunk by chunk (load_chunk), and its coefficients (from LDS)
+        PersistStage ls = cursor.cur;
         auto load_chunk = [&](int i) __attribute__((always_inline)) {
+            const PersistItem& lit = ls.it;
             const int oy1 = lit.ty * C3_TH - 1, ox1 = lit.tx * C3_TW - 1;
-            const char* base = reinterpret_cast<const char*>(a.in0) + (size_t)lit.img * a.in_rows * a.Win * 64;
-            const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, a.in_rows * a.Win * 64, 0x00020000);
-            const int base_off = ((oy1 + a.in_row_off) * a.Win + ox1) * 64;
+            const char* base = reinterpret_cast<const char*>(a.in0) + (size_t)lit.img * a.in_rows * a.Win * (2 * C) + ls.kc * 64;
+            const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, a.in_rows * a.Win * (2 * C) - ls.kc * 64, 0x00020000);
+            const int base_off = ((oy1 + a.in_row_off) * a.Win + ox1) * (2 * C);
             // tile-local bounds (wave-uniform): halo row py is readable iff y_lo <= py < y_hi, column px iff x_lo <= px < x_hi
             const int y_lo = max(a.iy_lo - oy1, 0), y_hi = min(a.iy_lo + a.iy_span - oy1, C3_IH);
             const int x_lo = max(-ox1, 0), x_hi = min(a.Win - ox1, C3_IW);
@@ -136,17 +149,17 @@ __global__ __launch_bounds__(C3_THREADS) void conv_c32_kernel(ConvArgs a) {
             }
             okm[i] = ok ? 0xffffffffu : 0u;
         };
-        auto load_coeffs = [&](int img) __attribute__((always_inline)) {      // (A, B) of this thread's 8 channels
-            const float4* ab = reinterpret_cast<const float4*>(smem + C3_COEF_OFF) + ((img - cursor.first_img) * 32 + c8 * 8) / 2;
+        auto load_coeffs = [&](const PersistStage& st) __attribute__((always_inline)) {      // (A, B) of this thread's 8 channels
+            const float4* ab = reinterpret_cast<const float4*>(smem + K::COEF_OFF) + ((st.it.img - cursor.first_img) * C + st.kc * 32 + c8 * 8) / 2;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float4 v = ab[e]; cA[2 * e] = v.x; cB[2 * e] = v.y; cA[2 * e + 1] = v.z; cB[2 * e + 1] = v.w; }
         };
         // Two chunks (16 channel values in 8 packed pairs) move through the transform STAGE BY STAGE (16 independent v_exp, then
         // 16 independent v_rcp: a single in-order wave hides a transcendental's latency only behind its own independent work);
-        // as soon as a pair has been transformed the same registers are reloaded with the NEXT item's pair, so every load has
-        // most of an item's time to land and the first pair of the next transform is the oldest request.  Straight-line code on
+        // as soon as a pair has been transformed the same registers are reloaded with the NEXT stage's pair, so every load has
+        // most of a stage's time to land and the first pair of the next transform is the oldest request.  Straight-line code on
         // purpose: with the reloads under a branch hipcc loses the order of the pending loads at the join and waits for all.
-        auto transform_item = [&](unsigned char* tile) __attribute__((always_inline)) {
+        auto transform_stage = [&](unsigned char* tile) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < C3_P_ITERS; i += 2) {
                 const unsigned wds[8] = {R[i].x, R[i].y, R[i].z, R[i].w, R[i + 1].x, R[i + 1].y, R[i + 1].z, R[i + 1].w};
@@ -188,19 +201,19 @@ __global__ __launch_bounds__(C3_THREADS) void conv_c32_kernel(ConvArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        // item 0 -> R; then every transform reloads R with the item after (past the last item the cursor stays on it: a
+        // stage 0 -> R; then every transform reloads R with the stage after (past the last stage the cursor stays on it: a
         // redundant reload of rows that are never used)
 #pragma unroll
         for (int i = 0; i < C3_P_ITERS; ++i) load_chunk(i);
-        load_coeffs(lit.img);
-        lit = cursor.next().it;
-        transform_item(smem);
-        c3_barrier();                                           // tile 0 is staged
-        for (int t = 0; t < n_items; ++t) {
-            // tile t + 1 (for t + 1 == n_items: the last item again, into the tile nobody reads any more)
-            load_coeffs(lit.img);
-            lit = cursor.next().it;
-            transform_item(smem + ((t + 1) & 1) * C3_IN_BYTES);   // the consumers finished reading this tile before the last barrier
+        load_coeffs(ls);
+        ls = cursor.next();
+        transform_stage(smem);
+        c3_barrier();                                           // tile of stage 0 is staged
+        for (int t = 0; t < n_stages; ++t) {
+            // tile of stage t + 1 (for t + 1 == n_stages: the last stage again, into the tile nobody reads any more)
+            load_coeffs(ls);
+            ls = cursor.next();
+            transform_stage(smem + ((t + 1) & 1) * C3_IN_BYTES);   // the consumers finished reading this tile before the last barrier
             c3_barrier();
         }
         return;
@@ -218,24 +231,29 @@ __global__ __launch_bounds__(C3_THREADS) void conv_c32_kernel(ConvArgs a) {
             const int p = (wave * 2 + m + ky) * C3_IW + r + kx;
             a_off[m][tap] = (p * 4 + (h ^ ((p >> 2) & 3))) * 16;
         }
-    const unsigned char* wb = smem + C3_W_OFF + (h * 32 + r) * 16;         // + (tap*4 + 2 cp) * 512
-    f32x16_t bias_acc;                    // the C operand of every item's first MFMAs: the accumulators start at the bias, no moves
-    {
-        const float* bl = reinterpret_cast<const float*>(smem + C3_BIAS_OFF);
+    const unsigned char* wb = smem + K::W_OFF + (h * C + r) * 16;         // + kc * W_STAGE + ((tap*4 + 2 cp) * C + j*32) * 16
+    const float* bias_lds = reinterpret_cast<const float*>(smem + K::BIAS_OFF);
+    f32x16_t bias_acc;                    // C = 32: the C operand of every item's first MFMAs (the accumulators start at the bias, no moves)
+    if constexpr (C == 32) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) bias_acc[i] = bl[16 * (i >> 3) + 8 * h + (i & 7)];     // permuted slab rows
+        for (int i = 0; i < 16; ++i) bias_acc[i] = bias_lds[16 * (i >> 3) + 8 * h + (i & 7)];     // permuted slab rows
     }
-    float* red_base = reinterpret_cast<float*>(smem + C3_RED_OFF);
+    float* red_base = reinterpret_cast<float*>(smem + K::RED_OFF);
     int st_img = -1, st_tile = 0, st_par = 0, red_par = 0;
-    auto flush_stats = [&]() {              // partials of the item finished before the last barrier: 8 groups of 4 couts
+    auto flush_stats = [&]() {              // partials of the item finished before the last barrier: 8 groups of C / 8 couts
         if (HEAD || st_img < 0) return;
         if (tid < 8) {
-            const float* red = red_base + st_par * C3_RED_HALF;
+            const float* red = red_base + st_par * K::RED_HALF;
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) {
-                const float* d = red + (w * 4 + (tid >> 1)) * 4 + 2 * (tid & 1);
-                s += d[0]; q += d[1];
+                if constexpr (C == 32) {           // groups of 4: a 16-B chunk holds two groups (sA, qA | sB, qB)
+                    const float* d = red + (w * NCC + (tid >> 1)) * 4 + 2 * (tid & 1);
+                    s += d[0]; q += d[1];
+                } else {                           // groups of 8: chunk cc = group cc, both pairs
+                    const float* d = red + (w * NCC + tid) * 4;
+                    s += d[0] + d[2]; q += d[1] + d[3];
+                }
             }
             float* st = a.stats + (((size_t)st_img * tiles_per_img + st_tile) * 8 + tid) * 2;
             st[0] = s; st[1] = q;
@@ -243,18 +261,18 @@ __global__ __launch_bounds__(C3_THREADS) void conv_c32_kernel(ConvArgs a) {
         st_img = -1;
     };
 
-    f32x16_t acc[2];
-    uint4 erv[2][2];
+    f32x16_t acc[2][NTL];
+    uint4 erv[2 * NTL][2];
     unsigned eoffs[2];
     bool einb[2];
     unsigned hin[2] = {0u, 0u};           // head: this lane's dword of the two image rows
     size_t hoff[2] = {0, 0};
     bool hok[2] = {false, false};
     PersistStage cs = cursor.cur;
-    c3_barrier();                                               // tile 0 is staged
+    int stage_no = 0;
+    c3_barrier();                                               // tile of stage 0 is staged
     for (int t = 0; t < n_items; ++t) {
         const PersistItem it = cs.it;
-        const unsigned char* ib = smem + (t & 1) * C3_IN_BYTES;
         flush_stats();
         {   // output / residual offsets of this lane's two pixels; the residual rows are requested before the MFMAs
             const int oyb = it.ty * C3_TH + wave * 2, ox = it.tx * C3_TW + r;
@@ -264,12 +282,12 @@ __global__ __launch_bounds__(C3_THREADS) void conv_c32_kernel(ConvArgs a) {
             for (int m = 0; m < 2; ++m) {
                 const int oy = oyb + m;
                 einb[m] = colok && oy < a.Hout;
-                eoffs[m] = ((unsigned)((min(oy, a.Hout - 1) * a.Wout + oxc) * 32) << 1) + (unsigned)(h * 16);
+                eoffs[m] = ((unsigned)((min(oy, a.Hout - 1) * a.Wout + oxc) * C) << 1) + (unsigned)(h * 16);
             }
             if constexpr (RESID) {
-                const char* rbase = reinterpret_cast<const char*>(a.resid) + (size_t)it.img * a.Hout * a.Wout * 64;
+                const char* rbase = reinterpret_cast<const char*>(a.resid) + (size_t)it.img * a.Hout * a.Wout * (2 * C);
 #pragma unroll
-                for (int g = 0; g < 2; ++g)
+                for (int g = 0; g < 2 * NTL; ++g)
 #pragma unroll
                     for (int m = 0; m < 2; ++m) erv[g][m] = *reinterpret_cast<const uint4*>(rbase + eoffs[m] + (unsigned)(g * 32));
             }
@@ -286,29 +304,52 @@ __global__ __launch_bounds__(C3_THREADS) void conv_c32_kernel(ConvArgs a) {
                 }
             }
         }
-        // 18 k-steps (tap, channel half): two pixel fragments + one weight fragment, read one k-step ahead of its MFMAs
-        bf16x8_t af[2][2], bf[2];
-        auto read_k = [&](int g, bf16x8_t (&pa)[2], bf16x8_t& pw) __attribute__((always_inline)) {
-            const int tap = g >> 1, cp = g & 1;
+        if constexpr (C != 32) {          // the accumulators start at the bias: straight from the LDS table (permuted slab rows)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) pa[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ib + (a_off[m][tap] ^ (cp << 5))));
-            pw = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wb + (tap * 4 + 2 * cp) * 512));
-        };
-        read_k(0, af[0], bf[0]);
-        if constexpr (!(C3_ABL & 4))
+            for (int j = 0; j < NTL; ++j)
 #pragma unroll
-        for (int g = 0; g < 18; ++g) {
-            if (g + 1 < 18) read_k(g + 1, af[(g + 1) & 1], bf[(g + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int q = 0; q < 4; ++q) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bias_lds + j * 32 + 16 * (q >> 1) + 8 * h + 4 * (q & 1));
 #pragma unroll
-            for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[g & 1], af[g & 1][m], g == 0 ? bias_acc : acc[m], 0, 0, 0);   // D[cout][pixel]
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int m = 0; m < 2; ++m) { acc[m][j][4 * q + 0] = bv.x; acc[m][j][4 * q + 1] = bv.y; acc[m][j][4 * q + 2] = bv.z; acc[m][j][4 * q + 3] = bv.w; }
+                }
         }
-        // ---- epilogue (conv_rb.hip's): accumulator i of lane (r, h) is cout 16 (i >> 3) + 8 h + (i & 7) ------------------------
+        // NKC stages of 18 k-steps (tap, channel half): two pixel fragments + NTL weight fragments, read one k-step ahead
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            const unsigned char* ib = smem + (stage_no & 1) * C3_IN_BYTES;
+            const unsigned char* wk = wb + kc * K::W_STAGE;
+            bf16x8_t af[2][2], bf[2][NTL];
+            auto read_k = [&](int g, bf16x8_t (&pa)[2], bf16x8_t (&pw)[NTL]) __attribute__((always_inline)) {
+                const int tap = g >> 1, cp = g & 1;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) pa[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ib + (a_off[m][tap] ^ (cp << 5))));
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) pw[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wk + ((tap * 4 + 2 * cp) * C + j * 32) * 16));
+            };
+            read_k(0, af[0], bf[0]);
+            if constexpr (!(C3_ABL & 4))
+#pragma unroll
+            for (int g = 0; g < 18; ++g) {
+                if (g + 1 < 18) read_k(g + 1, af[(g + 1) & 1], bf[(g + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j) {
+                        if constexpr (C == 32) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[g & 1][j], af[g & 1][m], (kc == 0 && g == 0) ? bias_acc : acc[m][j], 0, 0, 0);
+                        else acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[g & 1][j], af[g & 1][m], acc[m][j], 0, 0, 0);   // D[cout][pixel]
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            ++stage_no;
+            if (kc + 1 < NKC) { cs = cursor.next(); c3_barrier(); }      // the item's next stage: its tile is staged, this one is free
+        }
+        // ---- epilogue (conv_rb.hip's): accumulator i of n-tile j of lane (r, h) is cout 32 j + 16 (i >> 3) + 8 h + (i & 7) -----------
         if constexpr (HEAD) {
             // out = clamp(round(in + y)) for the 3 channels: the image bytes travel as dwords (one load and one store instruction
             // per row instead of three byte-wide ones each) and are re-sliced per pixel through a 192-byte wave-private LDS patch
-            unsigned char* hp = smem + C3_HEAD_OFF + wave * (2 * 2 * 96);
+            unsigned char* hp = smem + K::HEAD_OFF + wave * (2 * 2 * 96);
 #pragma unroll
             for (int m = 0; m < 2; ++m)
                 if (lane < 24) *reinterpret_cast<unsigned*>(hp + m * 96 + 4 * lane) = hin[m];
@@ -317,7 +358,7 @@ __global__ __launch_bounds__(C3_THREADS) void conv_c32_kernel(ConvArgs a) {
                 if (h == 0) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        float vv = (float)hp[m * 96 + 3 * r + c] + acc[m][c];          // the bias is already in the accumulator
+                        float vv = (float)hp[m * 96 + 3 * r + c] + acc[m][0][c];          // the bias is already in the accumulator
                         vv = fminf(fmaxf(vv, 0.f), 255.f);
                         hp[192 + m * 96 + 3 * r + c] = (unsigned char)(int)floorf(vv + 0.5f);
                     }
@@ -327,25 +368,30 @@ __global__ __launch_bounds__(C3_THREADS) void conv_c32_kernel(ConvArgs a) {
             for (int m = 0; m < 2; ++m)
                 if (hok[m]) *reinterpret_cast<unsigned*>(a.u8_out + hoff[m]) = *reinterpret_cast<const unsigned*>(hp + 192 + m * 96 + 4 * min(lane, 23));
         } else if constexpr (C3_ABL & 2) {
-            if (acc[0][0] + acc[1][5] == 1.2345f) a.out[0] = 1;
+            if (acc[0][0][0] + acc[1][NTL - 1][5] == 1.2345f) a.out[0] = 1;
         } else {
-            char* obase = reinterpret_cast<char*>(a.out) + (size_t)it.img * a.Hout * a.Wout * 64;
-            const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.Hout * a.Wout * 64, 0x00020000);
+            char* obase = reinterpret_cast<char*>(a.out) + (size_t)it.img * a.Hout * a.Wout * (2 * C);
+            const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.Hout * a.Wout * (2 * C), 0x00020000);
             const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
-            float* redw = red_base + red_par * C3_RED_HALF;
+            float* redw = red_base + red_par * K::RED_HALF;
             const float mf[2] = {einb[0] ? 1.f : 0.f, einb[1] ? 1.f : 0.f};      // a pixel outside the image counts for nothing
-            // v[2 pp + e] = (sum, sum of squares) of this lane's couts 16 pp + 8 h + 4 e .. + 3 over its two pixels
+            // 16-cout group g = (j, pp): this lane's 8 couts 32 j + 16 pp + 8 h .. + 7 = 16-B chunk cc = 4 j + 2 pp + h of its pixels
+            // C = 32 (GroupNorm groups of 4): vs/vq[2 g + e] = (sum, squares) of the chunk's couts 4 e .. 4 e + 3 -> 8 values
+            // C = 64 (groups of 8):           vs/vq[g] = of the whole chunk                                    -> 8 values
             float vs[4], vq[4];
 #pragma unroll
+            for (int j = 0; j < NTL; ++j)
+#pragma unroll
             for (int pp = 0; pp < 2; ++pp) {
+                const int g = 2 * j + pp;
                 float sA = 0.f, qA = 0.f, sB = 0.f, qB = 0.f;
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const f32x16_t& c = acc[m];
+                    const f32x16_t& c = acc[m][j];
                     unsigned w[4] = {c3_pack(c[8 * pp + 0], c[8 * pp + 1]), c3_pack(c[8 * pp + 2], c[8 * pp + 3]),
                                      c3_pack(c[8 * pp + 4], c[8 * pp + 5]), c3_pack(c[8 * pp + 6], c[8 * pp + 7])};
                     if constexpr (RESID) {
-                        const uint4 rr = erv[pp][m];
+                        const uint4 rr = erv[g][m];
                         const unsigned rw[4] = {rr.x, rr.y, rr.z, rr.w};
 #pragma unroll
                         for (int d = 0; d < 4; ++d) w[d] = c3_pack(c3_lo(w[d]) + c3_lo(rw[d]), c3_hi(w[d]) + c3_hi(rw[d]));
@@ -354,24 +400,26 @@ __global__ __launch_bounds__(C3_THREADS) void conv_c32_kernel(ConvArgs a) {
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
                         const bf16x2_t wv = __builtin_bit_cast(bf16x2_t, w[d]);
-                        if (d < 2) { ts0 = __builtin_amdgcn_fdot2_f32_bf16(wv, ones, ts0, false); tq0 = __builtin_amdgcn_fdot2_f32_bf16(wv, wv, tq0, false); }
+                        if (d < 2 || C != 32) { ts0 = __builtin_amdgcn_fdot2_f32_bf16(wv, ones, ts0, false); tq0 = __builtin_amdgcn_fdot2_f32_bf16(wv, wv, tq0, false); }
                         else { ts1 = __builtin_amdgcn_fdot2_f32_bf16(wv, ones, ts1, false); tq1 = __builtin_amdgcn_fdot2_f32_bf16(wv, wv, tq1, false); }
                     }
-                    sA = __builtin_fmaf(ts0, mf[m], sA); qA = __builtin_fmaf(tq0, mf[m], qA); sB = __builtin_fmaf(ts1, mf[m], sB); qB = __builtin_fmaf(tq1, mf[m], qB);
+                    sA = __builtin_fmaf(ts0, mf[m], sA); qA = __builtin_fmaf(tq0, mf[m], qA);
+                    if constexpr (C == 32) { sB = __builtin_fmaf(ts1, mf[m], sB); qB = __builtin_fmaf(tq1, mf[m], qB); }
                     const u32x4_t wv4 = {w[0], w[1], w[2], w[3]};
-                    __builtin_amdgcn_raw_buffer_store_b128(wv4, orsrc, einb[m] ? eoffs[m] + (unsigned)(pp * 32) : 0xffffffffu, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(wv4, orsrc, einb[m] ? eoffs[m] + (unsigned)(g * 32) : 0xffffffffu, 0, 0);
                 }
-                vs[2 * pp] = sA; vq[2 * pp] = qA; vs[2 * pp + 1] = sB; vq[2 * pp + 1] = qB;
+                if constexpr (C == 32) { vs[2 * pp] = sA; vq[2 * pp] = qA; vs[2 * pp + 1] = sB; vq[2 * pp + 1] = qB; }
+                else { vs[g] = sA; vq[g] = qA; }
             }
             // Sum of each of the 8 values over the 32 lanes of a half, TRANSPOSING for the first two steps: a lane keeps half of
             // its values and hands the other half to its partner (lane ^ 1, then lane ^ 2), so 8 -> 4 -> 2 values per lane; those two
             // take the plain steps over lane bits 2, 3 and 4.  28 instead of 56 cross-lane instructions; fixed order.  Lane l of a
-            // half ends with (kind = b0: sum / sum of squares) of the quads 2 b1 and 2 b1 + 1, i.e. of chunk pp = b1.
+            // half ends with (kind = b0: sum / sum of squares) of the values 2 b1 and 2 b1 + 1.
             {
                 const bool b0 = lane & 1, b1 = lane & 2;
                 auto xch = [&](float keep, float give, auto ctrl_tag) __attribute__((always_inline)) -> float {
-                    const int g = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), decltype(ctrl_tag)::value, 0xf, 0xf, false);
-                    return keep + __builtin_bit_cast(float, g);
+                    const int gg = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), decltype(ctrl_tag)::value, 0xf, 0xf, false);
+                    return keep + __builtin_bit_cast(float, gg);
                 };
                 float u[4], t2[2];
 #pragma unroll
@@ -382,8 +430,14 @@ __global__ __launch_bounds__(C3_THREADS) void conv_c32_kernel(ConvArgs a) {
                 t2[0] = c3_ror_add<8>(t2[0]); t2[1] = c3_ror_add<8>(t2[1]);
                 t2[0] = c3_swap16_add(t2[0]); t2[1] = c3_swap16_add(t2[1]);
                 if ((lane & 28) == 0) {
-                    float* d = redw + (wave * 4 + (b1 ? 2 : 0) + h) * 4 + (b0 ? 1 : 0);
-                    d[0] = t2[0]; d[2] = t2[1];
+                    if constexpr (C == 32) {      // values 2 b1 + e = (chunk pp = b1, half-chunk e): red[wave][cc = 2 pp + h][2 e + kind]
+                        float* d = redw + (wave * NCC + (b1 ? 2 : 0) + h) * 4 + (b0 ? 1 : 0);
+                        d[0] = t2[0]; d[2] = t2[1];
+                    } else {                      // values g = 2 b1 + e = (j = b1, pp = e): red[wave][cc = 4 j + 2 pp + h][kind]
+                        float* d = redw + (wave * NCC + (b1 ? 4 : 0) + h) * 4 + (b0 ? 1 : 0);
+                        d[0] = t2[0]; d[8] = t2[1];
+                        d[2] = 0.f; d[10] = 0.f;  // (the second pair of a chunk's slot is unused at C = 64: flush adds it)
+                    }
                 }
             }
             st_img = it.img; st_tile = it.tile; st_par = red_par; red_par ^= 1;
@@ -396,19 +450,27 @@ __global__ __launch_bounds__(C3_THREADS) void conv_c32_kernel(ConvArgs a) {
 
 }  // namespace
 
-// C = 32 ResBlock convs with the activation applied while staging (a.ab required), and the head: a.w = permuted-row slab
-// [kk = tap*4 + c8][32][8] (engine.cpp::make_conv d_wp), 16x32 tiles, a.stats = partials [img][tile][8][2] (not for the head)
-void conv_c32_launch(bool resid, bool head, const ConvArgs& a, hipStream_t stream) {
-    if (a.cout != 32 || a.cin0 != 32 || a.nkc != 1 || a.nblocks != 1 || !a.ab) fail(IRE_ERR_INTERNAL, "internal: conv_c32 arguments");
-    if (head ? (!a.u8_in || !a.u8_out) : !a.stats) fail(IRE_ERR_INTERNAL, "internal: conv_c32 arguments");
+// C = 32 / 64 ResBlock convs with the activation applied while staging (a.ab required), and the head: a.w = permuted-row slab
+// [k-chunk][kk = tap*4 + c8][C rows][8] (engine.cpp::make_conv d_wp), 16x32 tiles, a.stats = partials [img][tile][8][2] (not for
+// the head).  C = 64 holds the coefficients of at most 8 images in LDS: larger batches stay on conv_rb.hip (engine.cpp).
+void conv_pc_launch(bool resid, bool head, const ConvArgs& a, hipStream_t stream) {
+    const int C = a.cout;
+    if ((C != 32 && C != 64) || a.cin0 != C || a.nkc != C / 32 || a.nblocks != 1 || !a.ab) fail(IRE_ERR_INTERNAL, "internal: conv_pc arguments");
+    if (head ? (C != 32 || !a.u8_in || !a.u8_out) : !a.stats) fail(IRE_ERR_INTERNAL, "internal: conv_pc arguments");
+    if (a.nimg > (C == 32 ? PcCfg<32>::COEF_IMGS : PcCfg<64>::COEF_IMGS)) fail(IRE_ERR_INTERNAL, "internal: conv_pc batch");
     const int items = a.tiles_x * a.tiles_y * a.nimg;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int grid = items < cus ? items : cus;
-    if (head) hipLaunchKernelGGL((conv_c32_kernel<false, true>), dim3(grid), dim3(C3_THREADS), 0, stream, a);
-    else if (resid) hipLaunchKernelGGL((conv_c32_kernel<true, false>), dim3(grid), dim3(C3_THREADS), 0, stream, a);
-    else hipLaunchKernelGGL((conv_c32_kernel<false, false>), dim3(grid), dim3(C3_THREADS), 0, stream, a);
+    if (head) hipLaunchKernelGGL((conv_pc_kernel<32, false, true>), dim3(grid), dim3(C3_THREADS), 0, stream, a);
+    else if (C == 32) {
+        if (resid) hipLaunchKernelGGL((conv_pc_kernel<32, true, false>), dim3(grid), dim3(C3_THREADS), 0, stream, a);
+        else hipLaunchKernelGGL((conv_pc_kernel<32, false, false>), dim3(grid), dim3(C3_THREADS), 0, stream, a);
+    } else {
+        if (resid) hipLaunchKernelGGL((conv_pc_kernel<64, true, false>), dim3(grid), dim3(C3_THREADS), 0, stream, a);
+        else hipLaunchKernelGGL((conv_pc_kernel<64, false, false>), dim3(grid), dim3(C3_THREADS), 0, stream, a);
+    }
     IRE_HIP(hipGetLastError());
 }
 

@@ -92,7 +92,7 @@ Engine::Engine(const ire_config& cfg) {
     if (const char* v = std::getenv("IRE_UP_SUBPIX")) up_subpixel_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_UP_FUSE")) up_fuse_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_GN_FOLD")) gn_fold_ = std::atoi(v);
-    if (const char* v = std::getenv("IRE_C32")) c32_split_ = std::atoi(v);
+    if (const char* v = std::getenv("IRE_PC")) pc_split_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_HEAD_RB")) head_rb_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_DOWN_RB")) down_rb_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_FP8_MX")) fp8_mx_ = std::atoi(v);
@@ -875,7 +875,7 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
             a.fp8 = 1; a.w = reinterpret_cast<const unsigned short*>(cw.d_w8); a.bias = cw.d_bias8; a.oscale = cw.d_oscale;
         }
         conv_w4_launch(cw.kind == CONV_RB2, a, R.stream);
-    } else if (head_rb) { a.w = cw.d_wp; if (c32_split_) conv_c32_launch(false, true, a, R.stream); else conv_head_launch(a, R.stream); }
+    } else if (head_rb) { a.w = cw.d_wp; if (pc_split_ & 1) conv_pc_launch(false, true, a, R.stream); else conv_head_launch(a, R.stream); }
     else if (down_rb) { a.w = cw.d_wd; a.nkc = cw.cin / 32; a.nblocks = cw.cout / 64; conv_down_launch(a, R.stream); }
     else if (up_fused) {
         a.w = cw.d_wuf; a.w1 = cw.d_wsk; a.bias = cw.d_bias_uf; a.nkc = cw.cin / 32; a.nblocks = cw.cout / 32;
@@ -887,7 +887,9 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     else if (up_rb) { if (cw.d_wp) a.w = cw.d_wp; conv_up_launch(a, R.stream); }
     else if (rb && rb_tile_h_ == kRbTileH) {
         if (cw.d_wp) a.w = cw.d_wp;
-        if (c32_split_ && cw.cout == 32 && cw.cin == 32 && a.ab != nullptr && cw.d_wp) conv_c32_launch(cw.kind == CONV_RB2, false, a, R.stream);
+        const bool pc = a.ab != nullptr && cw.d_wp && cw.cin == cw.cout &&
+                        ((cw.cout == 32 && (pc_split_ & 1)) || (cw.cout == 64 && (pc_split_ & 2) && g.nimg <= 8));
+        if (pc) conv_pc_launch(cw.kind == CONV_RB2, false, a, R.stream);
         else conv_rb_launch(cw.kind == CONV_RB2, /*fused_act=*/a.ab != nullptr, a, R.stream);
     }
     else conv_launch(cw.kind, a, R.stream);
