@@ -32,7 +32,7 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 #ifndef C3_ABL
-#define C3_ABL 0     // timing ablations (results wrong by design): 1 no transform, 2 no epilogue, 4 no MFMA loop, 8 no input loads
+#define C3_ABL 0     // timing ablations (results wrong by design): 1 no transform, 2 no epilogue, 4 no MFMA loop, 8 no input loads, 16 no output stores, 32 no statistics, 64 no residual loads
 #endif
 constexpr int C3_CONS = 512, C3_PROD = 256, C3_THREADS = C3_CONS + C3_PROD;
 constexpr int C3_TH = 16, C3_TW = 32, C3_IH = C3_TH + 2, C3_IW = C3_TW + 2;
@@ -284,7 +284,12 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
                 einb[m] = colok && oy < a.Hout;
                 eoffs[m] = ((unsigned)((min(oy, a.Hout - 1) * a.Wout + oxc) * C) << 1) + (unsigned)(h * 16);
             }
-            if constexpr (RESID) {
+            if constexpr (RESID && (C3_ABL & 64)) {
+#pragma unroll
+                for (int g = 0; g < 2 * NTL; ++g)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) erv[g][m] = make_uint4(eoffs[m], g, 0x3f803f80u, m);
+            } else if constexpr (RESID) {
                 const char* rbase = reinterpret_cast<const char*>(a.resid) + (size_t)it.img * a.Hout * a.Wout * (2 * C);
 #pragma unroll
                 for (int g = 0; g < 2 * NTL; ++g)
@@ -397,6 +402,7 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
                         for (int d = 0; d < 4; ++d) w[d] = c3_pack(c3_lo(w[d]) + c3_lo(rw[d]), c3_hi(w[d]) + c3_hi(rw[d]));
                     }
                     float ts0 = 0.f, tq0 = 0.f, ts1 = 0.f, tq1 = 0.f;
+                    if constexpr (!(C3_ABL & 32))
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
                         const bf16x2_t wv = __builtin_bit_cast(bf16x2_t, w[d]);
@@ -406,7 +412,8 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
                     sA = __builtin_fmaf(ts0, mf[m], sA); qA = __builtin_fmaf(tq0, mf[m], qA);
                     if constexpr (C == 32) { sB = __builtin_fmaf(ts1, mf[m], sB); qB = __builtin_fmaf(tq1, mf[m], qB); }
                     const u32x4_t wv4 = {w[0], w[1], w[2], w[3]};
-                    __builtin_amdgcn_raw_buffer_store_b128(wv4, orsrc, einb[m] ? eoffs[m] + (unsigned)(g * 32) : 0xffffffffu, 0, 0);
+                    if constexpr (C3_ABL & 16) asm volatile("" :: "v"(wv4));
+                    else __builtin_amdgcn_raw_buffer_store_b128(wv4, orsrc, einb[m] ? eoffs[m] + (unsigned)(g * 32) : 0xffffffffu, 0, 0);
                 }
                 if constexpr (C == 32) { vs[2 * pp] = sA; vq[2 * pp] = qA; vs[2 * pp + 1] = sB; vq[2 * pp + 1] = qB; }
                 else { vs[g] = sA; vq[g] = qA; }
@@ -415,7 +422,7 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
             // its values and hands the other half to its partner (lane ^ 1, then lane ^ 2), so 8 -> 4 -> 2 values per lane; those two
             // take the plain steps over lane bits 2, 3 and 4.  28 instead of 56 cross-lane instructions; fixed order.  Lane l of a
             // half ends with (kind = b0: sum / sum of squares) of the values 2 b1 and 2 b1 + 1.
-            {
+            if constexpr (!(C3_ABL & 32)) {
                 const bool b0 = lane & 1, b1 = lane & 2;
                 auto xch = [&](float keep, float give, auto ctrl_tag) __attribute__((always_inline)) -> float {
                     const int gg = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), decltype(ctrl_tag)::value, 0xf, 0xf, false);
