@@ -80,9 +80,11 @@ void conv_f8_launch(bool resid, const ConvArgs& a, hipStream_t stream);
 void conv_down_launch(const ConvArgs& a, hipStream_t stream);
 // CONV_HEAD through the pipelined kernel (conv_rb.hip, HEAD variant): a.w = permuted-row slab (32 rows, 3 used), 16x32 tiles.
 void conv_head_launch(const ConvArgs& a, hipStream_t stream);
-// C = 32 / 64 ResBlock convs (fused activation) and the head as a producer / consumer workgroup, three waves per SIMD
-// (conv_pc.hip): a.w = permuted-row slab (C rows), 16x32 tiles, partials layout of conv_rb_launch; C = 64: a.nimg <= 8.
+// C = 32 .. 256 ResBlock convs (fused activation) and the head as a producer / consumer workgroup, three waves per SIMD
+// (conv_pc.hip): a.w = permuted-row slabs [n-block of min(C, 64) couts][k-chunk][kk][rows][8] (d_wp), a.nkc = C/32, a.nblocks =
+// max(1, C/64), 16x32 tiles, partials layout of conv_rb_launch.  conv_pc_fits: every workgroup's images fit its coefficient table.
 void conv_pc_launch(bool resid, bool head, const ConvArgs& a, hipStream_t stream);
+bool conv_pc_fits(int C, int tiles_per_img, int nimg);
 // CONV_UP as a sub-pixel convolution on the low-resolution grid (conv_up.hip): 4 output parities x 2x2 pre-summed taps.
 // a.Hin/Win = low-res source, a.Hout/Wout = 2x; a.nkc = Cin/32 (even), a.nblocks = cout/32, tiles of 16x32 LOW-res pixels.
 void conv_up_subpixel_launch(const ConvArgs& a, hipStream_t stream);

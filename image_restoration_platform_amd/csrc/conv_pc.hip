@@ -40,20 +40,25 @@ constexpr int C3_IN_CHUNKS = C3_IH * C3_IW * 4;                                 
 constexpr int C3_P_ITERS = (C3_IN_CHUNKS + C3_PROD - 1) / C3_PROD;               // 10 chunks per producer thread and stage
 constexpr int C3_IN_BYTES = C3_P_ITERS * C3_PROD * 16;                           // 40960: every chunk slot exists
 template <int C> struct PcCfg {
+    static constexpr int NT = C < 64 ? 32 : 64;                                 // couts per item
+    static constexpr int NBLK = C / NT;                                         // n-blocks (items per tile)
     static constexpr int NKC = C / 32;                                          // 32-channel stages per item
-    static constexpr int NTL = C / 32;                                          // 32-cout n-tiles per wave
-    static constexpr int W_STAGE = 36 * C * 16;                                 // [kk = tap*4 + c8][C rows] x 16 B per stage
-    static constexpr int W_CHUNKS = NKC * 36 * C;
+    static constexpr int NTL = NT / 32;                                         // 32-cout n-tiles per wave
+    static constexpr bool STREAM = C > 64;                                      // weight slabs streamed per stage (two LDS slots) instead of resident
+    static constexpr int W_STAGE = 36 * NT * 16;                                // [kk = tap*4 + c8][NT rows] x 16 B per stage
+    static constexpr int W_STAGE_CHUNKS = 36 * NT;
+    static constexpr int W_LDS = (STREAM ? 2 : NKC) * W_STAGE;
     static constexpr int W_OFF = 2 * C3_IN_BYTES;
-    static constexpr int BIAS_OFF = W_OFF + W_CHUNKS * 16;
-    static constexpr int NCC = C / 8;                                           // 16-B chunks of an output pixel
+    static constexpr int BIAS_OFF = W_OFF + W_LDS;
+    static constexpr int NCC = NT / 8;                                          // 16-B chunks of an item's couts per pixel
     static constexpr int RED_OFF = BIAS_OFF + C * 4;                            // 2 x [8 waves][NCC chunks][sA, qA, sB, qB]
     static constexpr int RED_HALF = 8 * NCC * 4;                                // floats
-    static constexpr int COEF_IMGS = C == 32 ? 64 : 8;                          // images whose (A, B) the LDS table holds
+    static constexpr int COEF_IMGS = C == 32 ? 64 : C == 64 ? 8 : 2;            // images whose (A, B) the LDS table holds
     static constexpr int COEF_OFF = RED_OFF + 2 * RED_HALF * 4;
     static constexpr int HEAD_OFF = COEF_OFF + COEF_IMGS * C * 2 * 4;           // head: [8 waves][in | out][2 rows][96 B]
     static constexpr int LDS = HEAD_OFF + (C == 32 ? 8 * 2 * 2 * 96 : 0);
     static_assert(LDS <= 160 * 1024, "LDS");
+    static_assert(!STREAM || W_STAGE_CHUNKS == 9 * C3_PROD, "a producer thread streams 9 weight chunks per stage");
 };
 
 __device__ __forceinline__ unsigned c3_pack(float a, float b) {
@@ -81,7 +86,7 @@ __device__ __forceinline__ void c3_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 template <int C, bool RESID, bool HEAD>
 __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
     using K = PcCfg<C>;
-    constexpr int NKC = K::NKC, NTL = K::NTL, NCC = K::NCC;
+    constexpr int NKC = K::NKC, NTL = K::NTL, NCC = K::NCC, NT = K::NT;
     static_assert(!HEAD || C == 32, "the head is a C = 32 layer");
     __shared__ __attribute__((aligned(16))) unsigned char smem[K::LDS];
     const int tid = threadIdx.x;
@@ -89,16 +94,17 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
     const int r = lane & 31, h = lane >> 5;
 
     const int tiles_per_img = a.tiles_x * a.tiles_y;
-    PersistCursor cursor(a.tiles_x, a.tiles_y, a.nimg, 1, NKC);    // one n-block; a cursor step is one 32-channel stage
+    PersistCursor cursor(a.tiles_x, a.tiles_y, a.nimg, K::NBLK, NKC);   // item = (tile, 64-cout block); a cursor step is one 32-channel stage
     const int n_items = cursor.my_items;
     if (n_items == 0) return;
     const int n_stages = n_items * NKC;
     if (a.gn_stats) gn_fold(a, smem, cursor.first_img, cursor.last_img, 512);
 
     {   // weights and bias stay in LDS for the whole kernel
-        const uint4* ws = reinterpret_cast<const uint4*>(a.w);
+        // resident weights: all of them; streamed: the slab of this workgroup's first stage (slot 0), the producers do the rest
+        const uint4* ws = reinterpret_cast<const uint4*>(a.w) + (K::STREAM ? (size_t)cursor.cur.it.nb * NKC * K::W_STAGE_CHUNKS : 0);
         uint4* wd = reinterpret_cast<uint4*>(smem + K::W_OFF);
-        for (int i = tid; i < K::W_CHUNKS; i += C3_THREADS) wd[i] = ws[i];
+        for (int i = tid; i < (K::STREAM ? 1 : NKC) * K::W_STAGE_CHUNKS; i += C3_THREADS) wd[i] = ws[i];
         if (tid < C) reinterpret_cast<float*>(smem + K::BIAS_OFF)[tid] = a.bias[tid];
         // the GroupNorm+FiLM coefficients of the images this workgroup's items belong to (gn_fold just wrote them, or
         // gn_finalize_kernel did): the producers read them from LDS, so that their only VMEM traffic is the input stream
@@ -159,9 +165,33 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
         // as soon as a pair has been transformed the same registers are reloaded with the NEXT stage's pair, so every load has
         // most of a stage's time to land and the first pair of the next transform is the oldest request.  Straight-line code on
         // purpose: with the reloads under a branch hipcc loses the order of the pending loads at the join and waits for all.
-        auto transform_stage = [&](unsigned char* tile) __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < C3_P_ITERS; i += 2) {
+        // streamed weights (C >= 128): this thread's 9 chunks of the slab of stage `ls` travel global -> registers -> LDS slot beside
+        // the tile, two chunks per transform pair through a ring of three register sets (requested two pairs before they are
+        // written: an L2 round trip), all compiler-counted loads in the same straight line as the input stream
+        uint4 wr0a, wr0b, wr1a, wr1b, wr2a, wr2b;                               // (named registers: an indexed or address-taken array goes to scratch)
+        const uint4* wsrc = nullptr;
+        auto w_issue = [&](auto p_tag) __attribute__((always_inline)) {          // chunks 2p, 2p + 1 (chunk k = tp + 256 k; k = 9 does not exist)
+            if constexpr (K::STREAM) {
+                constexpr int p = decltype(p_tag)::value;
+                const uint4 va = wsrc[tp + (2 * p) * C3_PROD];
+                uint4 vb = va;
+                if constexpr (2 * p + 1 < 9) vb = wsrc[tp + (2 * p + 1) * C3_PROD];
+                if constexpr (p % 3 == 0) { wr0a = va; wr0b = vb; } else if constexpr (p % 3 == 1) { wr1a = va; wr1b = vb; } else { wr2a = va; wr2b = vb; }
+            }
+        };
+        auto w_store = [&](auto p_tag, unsigned char* wslot) __attribute__((always_inline)) {
+            if constexpr (K::STREAM) {
+                constexpr int p = decltype(p_tag)::value;
+                uint4 va, vb;
+                if constexpr (p % 3 == 0) { va = wr0a; vb = wr0b; } else if constexpr (p % 3 == 1) { va = wr1a; vb = wr1b; } else { va = wr2a; vb = wr2b; }
+                reinterpret_cast<uint4*>(wslot)[tp + (2 * p) * C3_PROD] = va;
+                if constexpr (2 * p + 1 < 9) reinterpret_cast<uint4*>(wslot)[tp + (2 * p + 1) * C3_PROD] = vb;
+            }
+        };
+        auto transform_stage = [&](unsigned char* tile, unsigned char* wslot) __attribute__((always_inline)) {
+            w_issue(std::integral_constant<int, 0>{}); w_issue(std::integral_constant<int, 1>{});
+            auto pair = [&](auto pp_tag) __attribute__((always_inline)) {
+                constexpr int pp_ = decltype(pp_tag)::value, i = 2 * pp_;
                 const unsigned wds[8] = {R[i].x, R[i].y, R[i].z, R[i].w, R[i + 1].x, R[i + 1].y, R[i + 1].z, R[i + 1].w};
                 unsigned o[8];
                 if constexpr (C3_ABL & 1) {
@@ -198,22 +228,31 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
                     *reinterpret_cast<uint4*>(tile + lds_off[i + k]) = ov;
                 }
                 load_chunk(i); load_chunk(i + 1);
+                w_store(pp_tag, wslot);
+                if constexpr (pp_ + 2 < 5) w_issue(std::integral_constant<int, pp_ + 2>{});
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            };
+            pair(std::integral_constant<int, 0>{}); pair(std::integral_constant<int, 1>{}); pair(std::integral_constant<int, 2>{});
+            pair(std::integral_constant<int, 3>{}); pair(std::integral_constant<int, 4>{});
         };
         // stage 0 -> R; then every transform reloads R with the stage after (past the last stage the cursor stays on it: a
-        // redundant reload of rows that are never used)
+        // redundant reload of rows that are never used).  `ps` = the stage whose rows are in R = the stage being produced.
+        auto slab_of = [&](const PersistStage& st) -> const uint4* {
+            return reinterpret_cast<const uint4*>(a.w) + ((size_t)st.it.nb * NKC + st.kc) * K::W_STAGE_CHUNKS;
+        };
 #pragma unroll
         for (int i = 0; i < C3_P_ITERS; ++i) load_chunk(i);
         load_coeffs(ls);
+        wsrc = slab_of(ls);                                     // (slot 0 already holds it: the kernel prologue; written again, same bytes)
         ls = cursor.next();
-        transform_stage(smem);
-        c3_barrier();                                           // tile of stage 0 is staged
+        transform_stage(smem, smem + K::W_OFF);
+        c3_barrier();                                           // tile (and slab) of stage 0 are staged
         for (int t = 0; t < n_stages; ++t) {
-            // tile of stage t + 1 (for t + 1 == n_stages: the last stage again, into the tile nobody reads any more)
+            // tile / slab of stage t + 1 (for t + 1 == n_stages: the last stage again, into the slots nobody reads any more)
             load_coeffs(ls);
+            wsrc = slab_of(ls);
             ls = cursor.next();
-            transform_stage(smem + ((t + 1) & 1) * C3_IN_BYTES);   // the consumers finished reading this tile before the last barrier
+            transform_stage(smem + ((t + 1) & 1) * C3_IN_BYTES, smem + K::W_OFF + ((t + 1) & 1) * K::W_STAGE);   // the consumers finished reading these slots before the last barrier
             c3_barrier();
         }
         return;
@@ -231,7 +270,7 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
             const int p = (wave * 2 + m + ky) * C3_IW + r + kx;
             a_off[m][tap] = (p * 4 + (h ^ ((p >> 2) & 3))) * 16;
         }
-    const unsigned char* wb = smem + K::W_OFF + (h * C + r) * 16;         // + kc * W_STAGE + ((tap*4 + 2 cp) * C + j*32) * 16
+    const unsigned char* wb = smem + K::W_OFF + (h * NT + r) * 16;        // + slab offset + ((tap*4 + 2 cp) * NT + j*32) * 16
     const float* bias_lds = reinterpret_cast<const float*>(smem + K::BIAS_OFF);
     f32x16_t bias_acc;                    // C = 32: the C operand of every item's first MFMAs (the accumulators start at the bias, no moves)
     if constexpr (C == 32) {
@@ -239,10 +278,11 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
         for (int i = 0; i < 16; ++i) bias_acc[i] = bias_lds[16 * (i >> 3) + 8 * h + (i & 7)];     // permuted slab rows
     }
     float* red_base = reinterpret_cast<float*>(smem + K::RED_OFF);
-    int st_img = -1, st_tile = 0, st_par = 0, red_par = 0;
-    auto flush_stats = [&]() {              // partials of the item finished before the last barrier: 8 groups of C / 8 couts
+    int st_img = -1, st_tile = 0, st_nb = 0, st_par = 0, red_par = 0;
+    auto flush_stats = [&]() {              // partials of the item finished before the last barrier: its NT / (C / 8) groups
         if (HEAD || st_img < 0) return;
-        if (tid < 8) {
+        constexpr int G = C / 8, NGL = NT / G, CPG = G / 8;       // couts per group, groups per item, 16-B chunks per group (C >= 64)
+        if (tid < NGL) {
             const float* red = red_base + st_par * K::RED_HALF;
             float s = 0.f, q = 0.f;
 #pragma unroll
@@ -250,12 +290,15 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
                 if constexpr (C == 32) {           // groups of 4: a 16-B chunk holds two groups (sA, qA | sB, qB)
                     const float* d = red + (w * NCC + (tid >> 1)) * 4 + 2 * (tid & 1);
                     s += d[0]; q += d[1];
-                } else {                           // groups of 8: chunk cc = group cc, both pairs
-                    const float* d = red + (w * NCC + tid) * 4;
-                    s += d[0] + d[2]; q += d[1] + d[3];
+                } else {                           // groups of 8 / 16 / 32: CPG whole chunks each
+#pragma unroll
+                    for (int k = 0; k < CPG; ++k) {
+                        const float* d = red + (w * NCC + tid * CPG + k) * 4;
+                        s += d[0] + d[2]; q += d[1] + d[3];
+                    }
                 }
             }
-            float* st = a.stats + (((size_t)st_img * tiles_per_img + st_tile) * 8 + tid) * 2;
+            float* st = a.stats + (((size_t)st_img * tiles_per_img + st_tile) * 8 + (st_nb * NT) / G + tid) * 2;
             st[0] = s; st[1] = q;
         }
         st_img = -1;
@@ -282,7 +325,7 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
             for (int m = 0; m < 2; ++m) {
                 const int oy = oyb + m;
                 einb[m] = colok && oy < a.Hout;
-                eoffs[m] = ((unsigned)((min(oy, a.Hout - 1) * a.Wout + oxc) * C) << 1) + (unsigned)(h * 16);
+                eoffs[m] = ((unsigned)((min(oy, a.Hout - 1) * a.Wout + oxc) * C + it.nb * NT) << 1) + (unsigned)(h * 16);
             }
             if constexpr (RESID && (C3_ABL & 64)) {
 #pragma unroll
@@ -314,23 +357,23 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
             for (int j = 0; j < NTL; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 bv = *reinterpret_cast<const float4*>(bias_lds + j * 32 + 16 * (q >> 1) + 8 * h + 4 * (q & 1));
+                    const float4 bv = *reinterpret_cast<const float4*>(bias_lds + it.nb * NT + j * 32 + 16 * (q >> 1) + 8 * h + 4 * (q & 1));
 #pragma unroll
                     for (int m = 0; m < 2; ++m) { acc[m][j][4 * q + 0] = bv.x; acc[m][j][4 * q + 1] = bv.y; acc[m][j][4 * q + 2] = bv.z; acc[m][j][4 * q + 3] = bv.w; }
                 }
         }
         // NKC stages of 18 k-steps (tap, channel half): two pixel fragments + NTL weight fragments, read one k-step ahead
-#pragma unroll
+#pragma unroll NKC <= 2 ? NKC : 1
         for (int kc = 0; kc < NKC; ++kc) {
             const unsigned char* ib = smem + (stage_no & 1) * C3_IN_BYTES;
-            const unsigned char* wk = wb + kc * K::W_STAGE;
+            const unsigned char* wk = wb + (K::STREAM ? (stage_no & 1) : kc) * K::W_STAGE;
             bf16x8_t af[2][2], bf[2][NTL];
             auto read_k = [&](int g, bf16x8_t (&pa)[2], bf16x8_t (&pw)[NTL]) __attribute__((always_inline)) {
                 const int tap = g >> 1, cp = g & 1;
 #pragma unroll
                 for (int m = 0; m < 2; ++m) pa[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ib + (a_off[m][tap] ^ (cp << 5))));
 #pragma unroll
-                for (int j = 0; j < NTL; ++j) pw[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wk + ((tap * 4 + 2 * cp) * C + j * 32) * 16));
+                for (int j = 0; j < NTL; ++j) pw[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wk + ((tap * 4 + 2 * cp) * NT + j * 32) * 16));
             };
             read_k(0, af[0], bf[0]);
             if constexpr (!(C3_ABL & 4))
@@ -447,7 +490,7 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
                     }
                 }
             }
-            st_img = it.img; st_tile = it.tile; st_par = red_par; red_par ^= 1;
+            st_img = it.img; st_tile = it.tile; st_nb = it.nb; st_par = red_par; red_par ^= 1;
         }
         cs = cursor.next();
         c3_barrier();
@@ -457,27 +500,45 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
 
 }  // namespace
 
-// C = 32 / 64 ResBlock convs with the activation applied while staging (a.ab required), and the head: a.w = permuted-row slab
-// [k-chunk][kk = tap*4 + c8][C rows][8] (engine.cpp::make_conv d_wp), 16x32 tiles, a.stats = partials [img][tile][8][2] (not for
-// the head).  C = 64 holds the coefficients of at most 8 images in LDS: larger batches stay on conv_rb.hip (engine.cpp).
+// C = 32 .. 256 ResBlock convs with the activation applied while staging (a.ab required), and the head: a.w = permuted-row slabs
+// [n-block of NT = min(C, 64) couts][k-chunk][kk = tap*4 + c8][NT rows][8] (engine.cpp::make_conv d_wp), 16x32 tiles, a.stats =
+// partials [img][tile][8][2] (not for the head).  The producers' coefficient table holds 64 / 8 / 2 / 2 images (C = 32 / 64 /
+// 128 / 256): conv_pc_fits() tells the engine whether every workgroup of a launch stays within it.
+bool conv_pc_fits(int C, int tiles_per_img, int nimg) {
+    const int imgs = C == 32 ? PcCfg<32>::COEF_IMGS : C == 64 ? PcCfg<64>::COEF_IMGS : PcCfg<128>::COEF_IMGS;
+    if (nimg <= imgs) return true;
+    // the workgroups of XCD group x walk items [items x / X, items (x + 1) / X) (persist.hpp): images spanned by a range
+    const int nblk = C < 64 ? 1 : C / 64;
+    const long long ipi = (long long)tiles_per_img * nblk, items = ipi * nimg;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const long long G = items < cus ? items : cus, X = G < 8 ? G : 8;
+    for (long long x = 0; x < X; ++x) {
+        const long long lo = items * x / X, hi = items * (x + 1) / X;
+        if (hi > lo && (hi - 1) / ipi - lo / ipi + 1 > imgs) return false;
+    }
+    return true;
+}
+
 void conv_pc_launch(bool resid, bool head, const ConvArgs& a, hipStream_t stream) {
     const int C = a.cout;
-    if ((C != 32 && C != 64) || a.cin0 != C || a.nkc != C / 32 || a.nblocks != 1 || !a.ab) fail(IRE_ERR_INTERNAL, "internal: conv_pc arguments");
+    if ((C != 32 && C != 64 && C != 128 && C != 256) || a.cin0 != C || a.nkc != C / 32 || a.nblocks != (C < 64 ? 1 : C / 64) || !a.ab)
+        fail(IRE_ERR_INTERNAL, "internal: conv_pc arguments");
     if (head ? (C != 32 || !a.u8_in || !a.u8_out) : !a.stats) fail(IRE_ERR_INTERNAL, "internal: conv_pc arguments");
-    if (a.nimg > (C == 32 ? PcCfg<32>::COEF_IMGS : PcCfg<64>::COEF_IMGS)) fail(IRE_ERR_INTERNAL, "internal: conv_pc batch");
-    const int items = a.tiles_x * a.tiles_y * a.nimg;
+    if (!conv_pc_fits(C, a.tiles_x * a.tiles_y, a.nimg)) fail(IRE_ERR_INTERNAL, "internal: conv_pc batch");
+    const int items = a.tiles_x * a.tiles_y * a.nimg * a.nblocks;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int grid = items < cus ? items : cus;
-    if (head) hipLaunchKernelGGL((conv_pc_kernel<32, false, true>), dim3(grid), dim3(C3_THREADS), 0, stream, a);
-    else if (C == 32) {
-        if (resid) hipLaunchKernelGGL((conv_pc_kernel<32, true, false>), dim3(grid), dim3(C3_THREADS), 0, stream, a);
-        else hipLaunchKernelGGL((conv_pc_kernel<32, false, false>), dim3(grid), dim3(C3_THREADS), 0, stream, a);
-    } else {
-        if (resid) hipLaunchKernelGGL((conv_pc_kernel<64, true, false>), dim3(grid), dim3(C3_THREADS), 0, stream, a);
-        else hipLaunchKernelGGL((conv_pc_kernel<64, false, false>), dim3(grid), dim3(C3_THREADS), 0, stream, a);
-    }
+#define PC_GO(CC, RS, HD) hipLaunchKernelGGL((conv_pc_kernel<CC, RS, HD>), dim3(grid), dim3(C3_THREADS), 0, stream, a)
+    if (head) PC_GO(32, false, true);
+    else if (C == 32) { if (resid) PC_GO(32, true, false); else PC_GO(32, false, false); }
+    else if (C == 64) { if (resid) PC_GO(64, true, false); else PC_GO(64, false, false); }
+    else if (C == 128) { if (resid) PC_GO(128, true, false); else PC_GO(128, false, false); }
+    else { if (resid) PC_GO(256, true, false); else PC_GO(256, false, false); }
+#undef PC_GO
     IRE_HIP(hipGetLastError());
 }
 

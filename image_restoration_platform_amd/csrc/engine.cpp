@@ -865,7 +865,12 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
         } else flush_gn(R, g);
     }
     prof_begin(fam, R.stream, flops, bytes);
-    if (w4 && fp8_mx_ && cw.d_w8x != nullptr && a.ab != nullptr) {   // IRE_PRECISION_FP8: the 2x-rate block-scaled fp8 MFMA
+    const bool pc_hi = rb && rb_tile_h_ == kRbTileH && (pc_split_ & 4) && cw.cout >= 128 && cw.cin == cw.cout && a.ab != nullptr && cw.d_wp != nullptr &&
+                       cw.d_w8 == nullptr && conv_pc_fits(cw.cout, a.tiles_x * a.tiles_y, g.nimg);       // (fp8 engines keep conv_f8 / conv_w4)
+    if (pc_hi) {
+        a.w = cw.d_wp;
+        conv_pc_launch(cw.kind == CONV_RB2, false, a, R.stream);
+    } else if (w4 && fp8_mx_ && cw.d_w8x != nullptr && a.ab != nullptr) {   // IRE_PRECISION_FP8: the 2x-rate block-scaled fp8 MFMA
         a.fp8 = 1; a.w = reinterpret_cast<const unsigned short*>(cw.d_w8x); a.bias = cw.d_bias8; a.oscale = cw.d_oscale;
         a.nkc = cw.cin / 32; a.nblocks = cw.cout / 128;
         conv_f8_launch(cw.kind == CONV_RB2, a, R.stream);
@@ -888,7 +893,7 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     else if (rb && rb_tile_h_ == kRbTileH) {
         if (cw.d_wp) a.w = cw.d_wp;
         const bool pc = a.ab != nullptr && cw.d_wp && cw.cin == cw.cout &&
-                        ((cw.cout == 32 && (pc_split_ & 1)) || (cw.cout == 64 && (pc_split_ & 2) && g.nimg <= 8));
+                        ((cw.cout == 32 && (pc_split_ & 1)) || (cw.cout == 64 && (pc_split_ & 2))) && conv_pc_fits(cw.cout, a.tiles_x * a.tiles_y, g.nimg);
         if (pc) conv_pc_launch(cw.kind == CONV_RB2, false, a, R.stream);
         else conv_rb_launch(cw.kind == CONV_RB2, /*fused_act=*/a.ab != nullptr, a, R.stream);
     }
