@@ -25,7 +25,8 @@ SOURCES = [
      (["-DIRE_UP_D=" + os.environ["IRE_UP_D"]] if os.environ.get("IRE_UP_D") else [])),
     ("conv_down.hip", []),
     ("conv_f8.hip", []),
-    ("conv_pc.hip", (["-DC3_ABL=" + os.environ["C3_ABL"]] if os.environ.get("C3_ABL") else [])),
+    ("conv_pc.hip", (["-DC3_ABL=" + os.environ["C3_ABL"]] if os.environ.get("C3_ABL") else []) +
+     (["-DC3_PRIO=" + os.environ["C3_PRIO"]] if os.environ.get("C3_PRIO") else [])),
     ("gn.hip", []),
     ("fusion.hip", []),
     ("preprocess.hip", []),

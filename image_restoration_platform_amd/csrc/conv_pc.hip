@@ -31,6 +31,9 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
+#ifndef C3_PRIO
+#define C3_PRIO 1     // measured: priority 1 for the producer waves +0.5 % (911 -> 916 img/s); 3 the same
+#endif
 #ifndef C3_ABL
 #define C3_ABL 0     // timing ablations (results wrong by design): 1 no transform, 2 no epilogue, 4 no MFMA loop, 8 no input loads, 16 no output stores, 32 no statistics, 64 no residual loads
 #endif
@@ -77,10 +80,9 @@ __device__ __forceinline__ float c3_swap16_add(float v) {       // see conv_rb.h
     return x + y;
 }
 
-// The per-item barrier.  __syncthreads() is a workgroup-scope fence + s_barrier, and the fence drains vmcnt: the producers' loads
-// of the next tile and the consumers' output stores, both issued moments before, would be waited for at every item (measured:
-// +100 us per launch).  Only LDS traffic has to be ordered here: the tile a producer just wrote, the partials a consumer just
-// wrote; global loads and stores stay in flight across the barrier.
+// The per-stage barrier, spelled out: only LDS traffic has to be ordered (the tile a producer just wrote, the partials a consumer
+// just wrote); global loads and stores stay in flight across it.  (hipcc's __syncthreads() is the same two instructions on
+// gfx950 -- its workgroup-scope fence waits for lgkmcnt only -- measured equal; the asm form states the requirement.)
 __device__ __forceinline__ void c3_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int C, bool RESID, bool HEAD>
@@ -117,6 +119,9 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
 
     if (__builtin_amdgcn_readfirstlane(wave) >= 8) {
         // =============================== producers: waves 8..11 ===============================================================
+#if C3_PRIO
+        asm volatile("s_setprio %0" :: "n"(C3_PRIO));            // the producers are the youngest waves of their SIMD: without this they issue in the consumers' leftover slots
+#endif
         const int tp = tid - C3_CONS;
         const int c8 = tp & 3;                                   // this thread always stages the same 8-channel slice of a pixel
         // chunk i of this thread: halo-tile pixel p = (tp + 256 i) >> 2 -- constant for the whole kernel
