@@ -421,7 +421,10 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
             for (int m = 0; m < 2; ++m)
                 if (hok[m]) *reinterpret_cast<unsigned*>(a.u8_out + hoff[m]) = *reinterpret_cast<const unsigned*>(hp + 192 + m * 96 + 4 * min(lane, 23));
         } else if constexpr (C3_ABL & 2) {
-            if (acc[0][0][0] + acc[1][NTL - 1][5] == 1.2345f) a.out[0] = 1;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) asm volatile("" :: "v"(acc[m][j]));       // every accumulator stays live: no MFMA may be optimised away
         } else {
             char* obase = reinterpret_cast<char*>(a.out) + (size_t)it.img * a.Hout * a.Wout * (2 * C);
             const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.Hout * a.Wout * (2 * C), 0x00020000);
