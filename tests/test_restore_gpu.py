@@ -103,6 +103,24 @@ def test_alternate_kernel_schedules_agree(engine, weights0, env, monkeypatch):
     assert d.max() <= 2 and np.mean(d > 0) < 0.2, (int(d.max()), float(np.mean(d > 0)))
 
 
+@pytest.mark.parametrize("n,h,w", [(12, 32, 48), (20, 16, 32)])
+def test_many_small_images_per_call(weights0, n, h, w):
+    """Batches in which one workgroup's items span many images: the producer / consumer kernels keep the GroupNorm coefficients
+    of a workgroup's images in an LDS table (64 images at C = 32, 8 at C = 64); when a launch does not fit it the engine takes the
+    conv_rb path for that layer (conv_pc_fits).  Either way the result is the oracle's."""
+    from image_restoration_platform_amd.engine import Engine
+    imgs = synth.batch(n, h, w, start=5)
+    sc = _scores(imgs)
+    eng = Engine(device_index=0, max_batch=32)
+    try:
+        out = eng.restore(imgs, scores=sc)
+        one = eng.restore(imgs[3:4], scores=sc[3:4])
+    finally:
+        eng.close()
+    _assert_close(out, onet.restore(imgs, sc, weights0))
+    assert np.array_equal(one[0], out[3])                       # and a result does not depend on the batch around it
+
+
 def test_committed_golden(engine):
     imgs = np.load(os.path.join(HERE, "golden", "restore_golden_in.npy"))
     ref = np.load(os.path.join(HERE, "golden", "restore_golden_out.npy"))
