@@ -339,10 +339,12 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
                     for (int m = 0; m < 2; ++m) erv[g][m] = make_uint4(eoffs[m], g, 0x3f803f80u, m);
             } else if constexpr (RESID) {
                 const char* rbase = reinterpret_cast<const char*>(a.resid) + (size_t)it.img * a.Hout * a.Wout * (2 * C);
+                // row by row, a pixel's 16-B pieces back to back: the requests for the two halves of a 64-B sector (and the
+                // sectors of a line) leave the CU together
 #pragma unroll
-                for (int g = 0; g < 2 * NTL; ++g)
+                for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) erv[g][m] = *reinterpret_cast<const uint4*>(rbase + eoffs[m] + (unsigned)(g * 32));
+                    for (int g = 0; g < 2 * NTL; ++g) erv[g][m] = *reinterpret_cast<const uint4*>(rbase + eoffs[m] + (unsigned)(g * 32));
             }
             if constexpr (HEAD) {
                 // the wave's two rows of the ORIGINAL image, 32 pixels = 96 contiguous bytes each: 24 dwords per row, requested
