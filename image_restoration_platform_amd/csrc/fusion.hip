@@ -16,7 +16,9 @@
 // HBM-bound: k*3*H*W bytes in, 3*H*W out (+ the u8 luma planes: k*H*W written once, read <= twice).
 #include "fusion.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "engine.hpp"
@@ -31,7 +33,8 @@ constexpr int FM = 20;    // fine margin
 constexpr int NC = (2 * CR + 1) * (2 * CR + 1);  // 81
 constexpr int NF = (2 * FR + 1) * (2 * FR + 1);  // 49
 
-__global__ void fusion_luma_kernel(const uint8_t* __restrict__ rgb, int k, int H, int W, uint8_t* __restrict__ L,
+// `qp` = pitch of the quarter-res planes in bytes (W/4 rounded up to a multiple of 4: the SAD kernel stages dwords).
+__global__ void fusion_luma_kernel(const uint8_t* __restrict__ rgb, int k, int H, int W, int qp, uint8_t* __restrict__ L,
                                    uint8_t* __restrict__ Q) {
     const int Hq = H >> 2, Wq = W >> 2;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -47,93 +50,183 @@ __global__ void fusion_luma_kernel(const uint8_t* __restrict__ rgb, int k, int H
             L[p] = (uint8_t)l;
             sum += l;
         }
-    Q[i] = (uint8_t)((sum + 8u) >> 4);
+    Q[((size_t)v * Hq + yq) * qp + xq] = (uint8_t)((sum + 8u) >> 4);
 }
 
-// SAD of the reference plane against view v's plane at every candidate shift.
+// SAD of the reference plane against view v's plane at every candidate shift, and -- in the launch's last workgroup --
+// the winning shift of every view.
 // MODE 0: coarse on Q (all interior pixels, +-CR).  MODE 1: fine on L (every 2nd pixel, +-FR around 4*coarse).
+//
+// A workgroup walks tiles of SR sampled rows x TW reference pixels.  Per tile it stages the reference rows and the view's
+// rows (+-R, displaced by the coarse shift) in LDS as dwords -- both planes have a pitch that is a multiple of 4 and every
+// tile origin is too (margins 4 / 20, coarse shifts x 4), so the staging is dword loads -- and a thread then owns ONE
+// dword of reference pixels at a time: per candidate row it reads three view dwords and forms the nine (seven) shifted
+// windows with v_alignbyte, v_sad_u8 accumulating into that candidate's register (the fine search masks bytes 1 and 3:
+// every 2nd pixel).  The margins keep every window inside the plane: no clamping in the arithmetic (staging loads clamp
+// their ADDRESS at the plane's right / bottom edge; those bytes are masked).  Integer sums: any order gives the same result
+// (bit-exact against oracle/fusion.py).
+//
+// Workgroup sums go to the workgroup's own row of `part`; the last workgroup of the launch (ticket) adds the rows and picks
+// min (SAD, |dy|+|dx|, dy, dx) per view: no atomics on the 81 / 49 totals, no memset, no second launch.  (Same device-scope
+// store / wait / ticket sequence as classifier.hip.)
 template <int MODE>
-__global__ __launch_bounds__(256) void fusion_sad_kernel(const uint8_t* __restrict__ P, int k, int PH, int PW,
-                                                         const int* __restrict__ coarse, unsigned* __restrict__ sad) {
-    constexpr int R = MODE == 0 ? CR : FR, N = MODE == 0 ? NC : NF, M = MODE == 0 ? CR : FM, STEP = MODE == 0 ? 1 : 2;
-    __shared__ unsigned s_sad[N];
+struct SadCfg {
+    static constexpr int R = MODE == 0 ? CR : FR, N = MODE == 0 ? NC : NF, M = MODE == 0 ? CR : FM, STEP = MODE == 0 ? 1 : 2;
+    static constexpr int TW = MODE == 0 ? 128 : 256;        // tile width in reference pixels
+    static constexpr int SR = MODE == 0 ? 8 : 16;           // sampled reference rows per tile
+    static constexpr int TWD = TW / 4;                      // reference dwords per row
+    static constexpr int VR = (SR - 1) * STEP + 1 + 2 * R;  // view rows staged
+    static constexpr int VWD = TWD + 2;                     // view dwords per row (window offsets 0..8 from dword j: j .. j+2)
+    static constexpr int ITEMS = SR * TWD / 256;
+    static_assert(SR * TWD % 256 == 0 && M % 4 == 0, "tile shape");
+};
+
+constexpr int FUSE_SAD_GRID = 512;   // workgroups per view at most (= rows of `part` per view)
+
+template <int MODE>
+__global__ __launch_bounds__(256) void fusion_sad_kernel(const uint8_t* __restrict__ P, int k, int PH, int PW, int pitch,
+                                                         int* __restrict__ coarse, int* __restrict__ shifts,
+                                                         int* __restrict__ shifts_out, unsigned* __restrict__ part,
+                                                         unsigned* __restrict__ ticket) {
+    using C = SadCfg<MODE>;
+    constexpr int R = C::R, N = C::N, M = C::M, STEP = C::STEP, D = 2 * R + 1;
+    __shared__ unsigned s_ref[C::SR][C::TWD];
+    __shared__ unsigned s_view[C::VR][C::VWD];
+    __shared__ unsigned s_sad[2][N];
+    __shared__ int s_last;
+    const int tid = threadIdx.x;
     const int v = blockIdx.y + 1;
-    for (int i = threadIdx.x; i < N; i += 256) s_sad[i] = 0;
-    __syncthreads();
-    const int nx = (PW - 2 * M + STEP - 1) / STEP, ny = (PH - 2 * M + STEP - 1) / STEP;
+    for (int i = tid; i < 2 * N; i += 256) (&s_sad[0][0])[i] = 0;
     const int by = MODE == 0 ? 0 : 4 * coarse[v * 2], bx = MODE == 0 ? 0 : 4 * coarse[v * 2 + 1];
     const uint8_t* P0 = P;
-    const uint8_t* Pv = P + (size_t)v * PH * PW;
-    // per-thread partial SAD of every candidate shift in registers (N = 81 / 49), accumulated over this thread's pixels;
-    // lanes are then summed by DPP row rotations + permlane swaps and each wave adds N values to LDS once.  Integer sums:
-    // any order gives the same result (bit-exact against oracle/fusion.py).
-    unsigned acc[N];
+    const uint8_t* Pv = P + (size_t)v * PH * pitch;
+    const int pd = pitch >> 2;
+    const int tiles_x = (PW - 2 * M + C::TW - 1) / C::TW;
+    const int tiles_y = ((PH - 2 * M + STEP - 1) / STEP + C::SR - 1) / C::SR;
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int tile = blockIdx.x; tile < tiles_x * tiles_y; tile += gridDim.x) {   // uniform per workgroup
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int gy0 = M + ty * C::SR * STEP, gx0 = M + tx * C::TW;
+        __syncthreads();   // the previous tile's readers are done (and s_sad is zero on the first pass)
 #pragma unroll
-    for (int c = 0; c < N; ++c) acc[c] = 0u;
-    for (int base = blockIdx.x * 256; base < nx * ny; base += gridDim.x * 256) {   // uniform trip count per block
-        const int i = base + threadIdx.x;
-        const bool valid = i < nx * ny;
-        const int ii = valid ? i : 0;
-        const int y = M + (ii / nx) * STEP, x = M + (ii % nx) * STEP;
-        const int a = P0[(size_t)y * PW + x];
+        for (int it = 0; it < C::ITEMS; ++it) {
+            const int i = it * 256 + tid, r = i / C::TWD, j = i - r * C::TWD;
+            const int yy = min(gy0 + r * STEP, PH - 1), xd = min((gx0 >> 2) + j, pd - 1);
+            s_ref[r][j] = reinterpret_cast<const unsigned*>(P0 + (size_t)yy * pitch)[xd];
+        }
+        for (int i = tid; i < C::VR * C::VWD; i += 256) {
+            const int r = i / C::VWD, j = i - r * C::VWD;
+            const int yy = min(gy0 + by - R + r, PH - 1), xd = min(((gx0 + bx - 4) >> 2) + j, pd - 1);
+            s_view[r][j] = reinterpret_cast<const unsigned*>(Pv + (size_t)yy * pitch)[xd];
+        }
+        __syncthreads();
+        // The four waves split the candidate ROWS; a wave sweeps the tile once per row with its D accumulators.  (All N
+        // accumulators per thread in one unrolled pass is 4000 instructions executed once per workgroup: the instruction
+        // fetch, not the arithmetic, set that form's 35 us.)
+#pragma unroll 1
+        for (int dy = -R + wave; dy <= R; dy += 4) {
+            unsigned acc[D];
 #pragma unroll
-        for (int dy = -R; dy <= R; ++dy) {
-            const int yy = min(max(y + by + dy, 0), PH - 1);
-            const uint8_t* row = Pv + (size_t)yy * PW;
+            for (int c = 0; c < D; ++c) acc[c] = 0u;
+#pragma unroll 2
+            for (int i = lane; i < C::SR * C::TWD; i += 64) {
+                const int r = i / C::TWD, j = i - r * C::TWD;
+                const int y = gy0 + r * STEP, x = gx0 + 4 * j;
+                unsigned mask = 0;
+                if (y < PH - M) {
 #pragma unroll
-            for (int dx = -R; dx <= R; ++dx) {
-                const int xx = min(max(x + bx + dx, 0), PW - 1);
-                const int d = a - (int)row[xx];
-                acc[(dy + R) * (2 * R + 1) + dx + R] += valid ? (unsigned)(d < 0 ? -d : d) : 0u;
+                    for (int b = 0; b < 4; b += STEP)
+                        if (x + b < PW - M) mask |= 0xffu << (8 * b);
+                }
+                const unsigned a = s_ref[r][j] & mask;
+                const unsigned* row = &s_view[r * STEP + dy + R][j];
+                const unsigned w0 = row[0], w1 = row[1], w2 = row[2];
+#pragma unroll
+                for (int dx = -R; dx <= R; ++dx) {
+                    const int o = dx + 4;   // byte offset of the window from dword j
+                    const unsigned win = o < 4 ? __builtin_amdgcn_alignbyte(w1, w0, o & 3)
+                                       : o < 8 ? __builtin_amdgcn_alignbyte(w2, w1, o & 3) : w2;
+                    acc[dx + R] = __builtin_amdgcn_sad_u8(a, win & mask, acc[dx + R]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                unsigned val = acc[c];
+                val += (unsigned)__builtin_amdgcn_update_dpp(0, (int)val, 0x121, 0xf, 0xf, false);   // row_ror:1
+                val += (unsigned)__builtin_amdgcn_update_dpp(0, (int)val, 0x122, 0xf, 0xf, false);   // row_ror:2
+                val += (unsigned)__builtin_amdgcn_update_dpp(0, (int)val, 0x124, 0xf, 0xf, false);   // row_ror:4
+                val += (unsigned)__builtin_amdgcn_update_dpp(0, (int)val, 0x128, 0xf, 0xf, false);   // row_ror:8 -> row sums
+                if ((lane & 15) == 0) atomicAdd(&s_sad[0][(dy + R) * D + c], val);   // one lane per 16-lane row
             }
         }
     }
+    __syncthreads();
+    const int G = gridDim.x;
+    for (int i = tid; i < N; i += 256)
+        __hip_atomic_store(&part[((size_t)(v - 1) * G + blockIdx.x) * N + i], s_sad[0][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+        s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(G * gridDim.y - 1);
+    __syncthreads();
+    if (!s_last) return;
+    for (int i = tid; i < 2 * N; i += 256) (&s_sad[0][0])[i] = 0;
+    __syncthreads();
+    const int total = (k - 1) * G * N;
+    for (int base = 0; base < total; base += 256 * 8) {    // eight loads in flight per thread (one round trip each otherwise);
+        unsigned t[8];                                     // LDS atomics on N addresses per view
 #pragma unroll
-    for (int c = 0; c < N; ++c) {
-        unsigned val = acc[c];
-        val += (unsigned)__builtin_amdgcn_update_dpp(0, (int)val, 0x121, 0xf, 0xf, false);   // row_ror:1
-        val += (unsigned)__builtin_amdgcn_update_dpp(0, (int)val, 0x122, 0xf, 0xf, false);   // row_ror:2
-        val += (unsigned)__builtin_amdgcn_update_dpp(0, (int)val, 0x124, 0xf, 0xf, false);   // row_ror:4
-        val += (unsigned)__builtin_amdgcn_update_dpp(0, (int)val, 0x128, 0xf, 0xf, false);   // row_ror:8 -> row sums
-        acc[c] = val;
-    }
-    if ((threadIdx.x & 15) == 0) {            // one lane per 16-lane row
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * 256 + tid;
+            t[u] = i < total ? __hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        }
 #pragma unroll
-        for (int c = 0; c < N; ++c) atomicAdd(&s_sad[c], acc[c]);
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * 256 + tid;
+            if (i < total) atomicAdd(&s_sad[i / (G * N)][i % N], t[u]);
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < N; i += 256)
-        if (s_sad[i]) atomicAdd(&sad[(v - 1) * N + i], s_sad[i]);
+    if (tid == 0) {
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-cleaning
+        if (MODE == 0) { coarse[0] = 0; coarse[1] = 0; }
+        else {
+            shifts[0] = 0; shifts[1] = 0;
+            if (shifts_out) { shifts_out[0] = 0; shifts_out[1] = 0; }
+        }
+    }
+    if (wave < k - 1) {   // one wave per view: min over (SAD, |dy|+|dx|, dy, dx) as one 64-bit key (candidate index ascends with (dy, dx))
+        const int vv = wave + 1;
+        unsigned long long best = ~0ull;
+        for (int c = lane; c < N; c += 64) {
+            const int dy = c / D - R, dx = c % D - R;
+            const unsigned man = (unsigned)((dy < 0 ? -dy : dy) + (dx < 0 ? -dx : dx));
+            const unsigned long long key = ((unsigned long long)s_sad[vv - 1][c] << 16) | (man << 8) | (unsigned)c;
+            best = key < best ? key : best;
+        }
+        for (int off = 32; off; off >>= 1) {
+            const unsigned long long o = __shfl_xor(best, off);
+            best = o < best ? o : best;
+        }
+        if (lane == 0) {
+            const int c = (int)(best & 0xffu), bdy = c / D - R, bdx = c % D - R;
+            if (MODE == 0) { coarse[vv * 2] = bdy; coarse[vv * 2 + 1] = bdx; }
+            else {
+                const int sy = 4 * coarse[vv * 2] + bdy, sx = 4 * coarse[vv * 2 + 1] + bdx;
+                shifts[vv * 2] = sy; shifts[vv * 2 + 1] = sx;
+                if (shifts_out) { shifts_out[vv * 2] = sy; shifts_out[vv * 2 + 1] = sx; }
+            }
+        }
+    }
 }
 
-template <int MODE>
-__global__ void fusion_pick_kernel(const unsigned* __restrict__ sad, int k, int* __restrict__ coarse,
-                                   int* __restrict__ shifts) {
-    constexpr int R = MODE == 0 ? CR : FR, N = MODE == 0 ? NC : NF;
-    const int v = threadIdx.x + 1;
-    if (threadIdx.x == 0) {
-        if (MODE == 0) { coarse[0] = 0; coarse[1] = 0; }
-        else { shifts[0] = 0; shifts[1] = 0; }
-    }
-    if (v >= k) return;
-    unsigned best = 0xffffffffu;
-    int bdy = 0, bdx = 0, bman = 1 << 30;
-    for (int dy = -R; dy <= R; ++dy)
-        for (int dx = -R; dx <= R; ++dx) {
-            const unsigned s = sad[(v - 1) * N + (dy + R) * (2 * R + 1) + dx + R];
-            const int man = (dy < 0 ? -dy : dy) + (dx < 0 ? -dx : dx);
-            // lexicographic (SAD, |dy|+|dx|, dy, dx); the scan order already yields ascending (dy, dx)
-            if (s < best || (s == best && man < bman)) { best = s; bdy = dy; bdx = dx; bman = man; }
-        }
-    if (MODE == 0) { coarse[v * 2] = bdy; coarse[v * 2 + 1] = bdx; }
-    else { shifts[v * 2] = 4 * coarse[v * 2] + bdy; shifts[v * 2 + 1] = 4 * coarse[v * 2 + 1] + bdx; }
-}
+struct FuseWlut { unsigned w[256]; };   // the blend weights ride in the kernel arguments: no host-to-device copy
 
 __global__ __launch_bounds__(256) void fusion_blend_kernel(const uint8_t* __restrict__ rgb, int k, int H, int W,
                                                            const int* __restrict__ shifts,
-                                                           const unsigned* __restrict__ wlut, uint8_t* __restrict__ out) {
+                                                           const FuseWlut wlut, uint8_t* __restrict__ out) {
     __shared__ unsigned s_w[256];
-    s_w[threadIdx.x] = wlut[threadIdx.x];
+    s_w[threadIdx.x] = wlut.w[threadIdx.x];
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= H * W) return;
@@ -180,31 +273,37 @@ void check_fuse_args(int k, int h, int w) {
 
 void Engine::fuse_launch(const uint8_t* d_views, int k, int h, int w, const unsigned* host_wlut, uint8_t* d_out,
                          int32_t* d_shifts, hipStream_t s) {
-    const size_t px = (size_t)h * w, qpx = (size_t)(h / 4) * (w / 4);
+    const size_t px = (size_t)h * w;
+    const int hq = h / 4, wq = w / 4, qp = (wq + 3) & ~3;
     if (fuse_cap_px_ < px) {
         IRE_HIP(hipDeviceSynchronize());
         for (void* p : {(void*)d_fL_, (void*)d_fQ_, (void*)d_fsad_, (void*)d_fmisc_}) if (p) (void)hipFree(p);
         d_fL_ = (uint8_t*)dalloc(3 * px);
-        d_fQ_ = (uint8_t*)dalloc(3 * qpx);
-        d_fsad_ = (unsigned*)dalloc(sizeof(unsigned) * 2 * (NC + NF));
-        d_fmisc_ = (int*)dalloc(sizeof(int) * (6 + 6 + 256));   // coarse[3][2], shifts[3][2], wlut[256]
+        d_fQ_ = (uint8_t*)dalloc(3 * ((size_t)h / 4) * (((size_t)w / 4 + 3) & ~(size_t)3) + 64);   // pitch: a multiple of 4
+        d_fsad_ = (unsigned*)dalloc(sizeof(unsigned) * 2 * FUSE_SAD_GRID * NC);   // per-workgroup SAD rows (coarse and fine take turns)
+        d_fmisc_ = (int*)dalloc(sizeof(int) * (6 + 6 + 4));   // coarse[3][2], shifts[3][2], ticket
+        IRE_HIP(hipMemsetAsync(d_fmisc_, 0, sizeof(int) * (6 + 6 + 4), s));   // the ticket starts at zero; the kernels reset it
         fuse_cap_px_ = px;
     }
     int* d_coarse = d_fmisc_;
     int* d_sh = d_fmisc_ + 6;
-    unsigned* d_wlut = reinterpret_cast<unsigned*>(d_fmisc_ + 12);
+    unsigned* d_ticket = reinterpret_cast<unsigned*>(d_fmisc_ + 12);
+    FuseWlut lut;
+    std::memcpy(lut.w, host_wlut, sizeof(lut.w));
     prof_begin(FAM_FUSION, s, 0, (double)(k + 1) * px * 3);
-    IRE_HIP(hipMemcpyAsync(d_wlut, host_wlut, 256 * sizeof(unsigned), hipMemcpyHostToDevice, s));
-    IRE_HIP(hipMemsetAsync(d_fsad_, 0, sizeof(unsigned) * 2 * (NC + NF), s));
-    const int nq = k * (int)qpx;
-    hipLaunchKernelGGL(fusion_luma_kernel, dim3(ceil_div(nq, 256)), dim3(256), 0, s, d_views, k, h, w, d_fL_, d_fQ_);
-    hipLaunchKernelGGL(fusion_sad_kernel<0>, dim3(128, k - 1), dim3(256), 0, s, d_fQ_, k, h / 4, w / 4, d_coarse, d_fsad_);
-    hipLaunchKernelGGL(fusion_pick_kernel<0>, dim3(1), dim3(64), 0, s, d_fsad_, k, d_coarse, d_sh);
-    hipLaunchKernelGGL(fusion_sad_kernel<1>, dim3(512, k - 1), dim3(256), 0, s, d_fL_, k, h, w, d_coarse, d_fsad_ + 2 * NC);
-    hipLaunchKernelGGL(fusion_pick_kernel<1>, dim3(1), dim3(64), 0, s, d_fsad_ + 2 * NC, k, d_coarse, d_sh);
-    hipLaunchKernelGGL(fusion_blend_kernel, dim3(ceil_div((int)px, 256)), dim3(256), 0, s, d_views, k, h, w, d_sh, d_wlut, d_out);
+    const int nq = k * hq * wq;
+    hipLaunchKernelGGL(fusion_luma_kernel, dim3(ceil_div(nq, 256)), dim3(256), 0, s, d_views, k, h, w, qp, d_fL_, d_fQ_);
+    auto tiles = [](int ph, int pw, int m, int step, int tw, int sr) {
+        return ceil_div(pw - 2 * m, tw) * ceil_div(ceil_div(ph - 2 * m, step), sr);
+    };
+    const int g0 = std::min(FUSE_SAD_GRID, tiles(hq, wq, CR, 1, SadCfg<0>::TW, SadCfg<0>::SR));
+    const int g1 = std::min(FUSE_SAD_GRID, tiles(h, w, FM, 2, SadCfg<1>::TW, SadCfg<1>::SR));
+    hipLaunchKernelGGL(fusion_sad_kernel<0>, dim3(g0, k - 1), dim3(256), 0, s, d_fQ_, k, hq, wq, qp, d_coarse, d_sh, (int*)nullptr,
+                       d_fsad_, d_ticket);
+    hipLaunchKernelGGL(fusion_sad_kernel<1>, dim3(g1, k - 1), dim3(256), 0, s, d_fL_, k, h, w, w, d_coarse, d_sh, (int*)d_shifts,
+                       d_fsad_, d_ticket);
+    hipLaunchKernelGGL(fusion_blend_kernel, dim3(ceil_div((int)px, 256)), dim3(256), 0, s, d_views, k, h, w, d_sh, lut, d_out);
     IRE_HIP(hipGetLastError());
-    if (d_shifts) IRE_HIP(hipMemcpyAsync(d_shifts, d_sh, sizeof(int) * 2 * k, hipMemcpyDeviceToDevice, s));
     prof_end(s);
 }
 

@@ -15,6 +15,8 @@ pytestmark = pytest.mark.gpu
     (96, 96, ((0, 0), (-16, 15))),                   # two views, near the +-16 coarse limit
     (256, 256, ((0, 0), (0, 0), (1, -1))),
     (64, 64, ((0, 0), (2, 2), (-3, 1))),             # minimum size
+    (200, 328, ((0, 0), (-7, 9), (11, -13))),        # quarter-res width 82: padded pitch, ragged tiles on both axes
+    (72, 72, ((0, 0), (3, -2))),                     # quarter-res plane 18 x 18
 ])
 def test_bit_exact_vs_oracle(engine, h, w, shifts):
     views = synth.fusion_views(h, w, shifts=shifts)
@@ -58,6 +60,14 @@ def test_device_path_and_errors(engine):
         engine.fuse(views[:1], 0.1)                                  # k = 1
     with pytest.raises(EngineError):
         engine.fuse(np.zeros((2, 40, 64, 3), np.uint8), 0.1)        # too small
+
+
+def test_fusion_more_tiles_than_workgroups(engine):
+    """2304^2: the fine search has 639 tiles for at most 512 workgroups per view -- the tile loop and the row reduction."""
+    views = synth.fusion_views(2304, 2304, shifts=((0, 0), (9, -14)))
+    out, sh = engine.fuse(views, noise_score=0.1)
+    ref, rsh = ofu.fuse(views, 0.1)
+    assert np.array_equal(sh, rsh) and np.array_equal(out, ref)
 
 
 def test_fusion_full_size(engine):
