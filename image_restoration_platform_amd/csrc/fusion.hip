@@ -121,8 +121,8 @@ __global__ __launch_bounds__(256) void fusion_sad_kernel(const uint8_t* __restri
         }
         __syncthreads();
         // The four waves split the candidate ROWS; a wave sweeps the tile once per row with its D accumulators.  (All N
-        // accumulators per thread in one unrolled pass is 4000 instructions executed once per workgroup: the instruction
-        // fetch, not the arithmetic, set that form's 35 us.)
+        // accumulators per thread in one unrolled pass is 4400 instructions executed once, one wave per SIMD: 35 us per
+        // launch against 12-18 us for this form, profiles/r02_experiments.md.)
 #pragma unroll 1
         for (int dy = -R + wave; dy <= R; dy += 4) {
             unsigned acc[D];
