@@ -113,6 +113,7 @@ struct Geo {
 
 struct ProfRec {
     int fam;
+    bool own_e0 = true;   // false: e0 is the previous record's e1 (back-to-back profiled launches share the event)
     hipEvent_t e0, e1;
     double flops, bytes;
 };
@@ -277,6 +278,8 @@ private:
     std::map<std::string, std::vector<float>> captured_;
     int prof_on_ = 0;
     bool prof_open_ = false;
+    bool prof_chain_ = false;          // the stream's last operation is prof_.back()'s end event (prof_chain_stream_): the next record starts there
+    hipStream_t prof_chain_stream_ = nullptr;
     std::vector<ProfRec> prof_;
     std::vector<hipEvent_t> ev_pool_;
     double prof_ms_[FAM_COUNT] = {}, prof_flops_[FAM_COUNT] = {}, prof_bytes_[FAM_COUNT] = {};
