@@ -300,9 +300,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
         for (int g = 0; g + 1 < RD; ++g) load_resid(g, rv[g]);
     };
     // ---- one stage = 16 input channels: 9 k-steps (taps) of 16 MFMAs.  Pipeline (s = this stage):
-    //   * weights: three LDS slabs; the slab of stage s+2 is fetched by LDS-DMA during stage s (k-steps 4..8)
+    //   * weights: three LDS slabs; the slab of stage s+2 is fetched by LDS-DMA during stage s (k-steps 4, 5)
     //   * input:   two LDS tiles; one register set R holds stage s+1 (loaded during stage s-1); during k-steps 4..8 chunk i
-    //              goes R -> LDS tile (s+1)&1 and R.v[i] is reloaded with stage s+2
+    //              (k-step 4 + i) goes R -> LDS tile (s+1)&1 and R.v[i] is reloaded with stage s+2
     //   * k-steps 0..3 issue no VMEM at all; the single wait (vmcnt(0) at k-step 4) therefore only sees operations issued
     //     at least four k-steps earlier, and nothing is waited for at the stage end but the barrier.
     Regs R;
@@ -343,7 +343,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
             if (st + 1 < W4_NSTEPS && !(DBG & 2)) read_frags(st + 1, bfr[(st + 1) & 1], afr[(st + 1) & 1]);
             if (st == 4) {
                 // everything issued during the previous stage (R loads, slab s+1, epilogue stores) has had >= 4 k-steps
+                stamp(6);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                stamp(7);
 #pragma unroll
                 for (int i = 0; i < C::IN_ITERS; ++i) asm volatile("" : "+v"(R.v[i]));
                 if constexpr (FUSED) {            // coefficients of the data now in R (fetched with it, one stage ago)
@@ -370,15 +372,18 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
                     store_chunk(i, R, in_nxt);                           // stage s+1 input -> other tile
                     load_chunk(sq2, i, R);                              // stage s+2 input -> R.v[i]
                 }
-                if (FUSED && i == C::IN_ITERS) cnext = fetch_coeffs(sq2);   // after the last use of the old coefficients' data
-                if constexpr (!(DBG & 32)) {                            // slab s+2: 9 DMA issues over 5 k-steps
+                if (FUSED && i == 0) cnext = fetch_coeffs(sq2);   // after the last use of the old coefficients (stage_coeffs at k-step 4)
+                // slab s+2: all DMA issues in k-steps 4 and 5, so that the stage's LAST VMEM operation is the third input chunk at
+                // k-step 6 -- seven k-steps of flight before the next stage's vmcnt(0); spread over k-steps 4..8 the last issue had
+                // four MFMA-only k-steps (~1 us) and the wait stalled: RB1 / RB2 182 / 200 -> 176.5 / 196 us
+                if constexpr (!(DBG & 32)) {
                     const unsigned char* ws = wslab(sq2);
                     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
                     // branch-free issue (a CFG merge here makes hipcc drain vmcnt): waves past the slab's end re-fetch a
                     // chunk group another wave also fetches (same bytes, same destination)
                     static_assert(C::W_CHUNKS >= C::THREADS, "slab >= one workgroup-wide DMA issue");
 #pragma unroll
-                    for (int d = 2 * i; d < 2 * i + 2 && d < C::W_ITERS; ++d) {
+                    for (int d = 5 * i; i < 2 && d < 5 * i + 5 && d < C::W_ITERS; ++d) {
                         int cbase = d * C::THREADS + wave_u * 64;
                         if ((d + 1) * C::THREADS > C::W_CHUNKS) cbase = cbase >= C::W_CHUNKS ? cbase - C::W_CHUNKS : cbase;   // wraps to a 64-aligned group
                         w4_glds16(ws + (size_t)(cbase + lane) * 16, w_dst_lds + cbase * 16);
