@@ -340,6 +340,12 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
         read_frags(0, bfr[0], afr[0]);
 #pragma unroll
         for (int st = 0; st < W4_NSTEPS; ++st) {
+            // progress feedback: a wave early in its stage outranks one that is further along.  (The SIMD's arbitration otherwise
+            // favours the older of its two waves: it runs ahead, idles ~a quarter of every stage at the barrier, and the younger
+            // one then runs without a partner to fill its stalls -- tools/s2_stamps.sh.  A static priority only swaps the roles.)
+            if (WAVES == 8 && st == 0) __builtin_amdgcn_s_setprio(3);
+            if (WAVES == 8 && st == 3) __builtin_amdgcn_s_setprio(2);
+            if (WAVES == 8 && st == 6) __builtin_amdgcn_s_setprio(1);
             if (st + 1 < W4_NSTEPS && !(DBG & 2)) read_frags(st + 1, bfr[(st + 1) & 1], afr[(st + 1) & 1]);
             if (st == 4) {
                 // everything issued during the previous stage (R loads, slab s+1, epilogue stores) has had >= 4 k-steps
