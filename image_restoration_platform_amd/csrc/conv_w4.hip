@@ -138,22 +138,32 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
     const int b_off = (h * NT + r) * EB;
 
     // one 16-B chunk per thread and call: chunk idx = tid + i*256 of the (18 x 34 px) x 2 halves tile of stage si
-    auto load_chunk = [&](const StageInfo& si, int i, Regs& R) {
-        const W4Item& it = si.it;
+    // A thread's chunks sit at the same tile position in every stage of an item: their byte offsets within the image (and
+    // whether they are inside it) are computed once per ITEM (item_offsets, when the prefetch cursor sq2 enters a new item:
+    // ~25 VALU instructions per chunk) and a stage's request is base(item, kc) + offset.
+    unsigned coff[C::IN_ITERS], cok = 0;
+    auto item_offsets = [&](const W4Item& it) {
         const int oy1 = it.ty * W4_TH - 1, ox1 = it.tx * W4_TW - 1;
-        const char* base = reinterpret_cast<const char*>(a.in0) + (size_t)it.img * a.in_rows * a.Win * Cin * 2 + si.kc * 32;
-        int t2 = tid;
-        asm volatile("" : "+v"(t2));
-        const int p = (t2 + i * C::THREADS) >> 1;
-        const int py = p / W4_IW, px = p - py * W4_IW;
-        const int iy = oy1 + py, ix = ox1 + px;
-        const int WV = UPS ? a.Wout : a.Win;
-        const int cy = min(max(iy, a.iy_lo), a.iy_lo + a.iy_span - 1), cx = min(max(ix, 0), WV - 1);
-        const bool ok = iy == cy && ix == cx;
-        const int sy = (UPS ? (cy >> 1) : cy) + a.in_row_off, sx = UPS ? (cx >> 1) : cx;
-        const unsigned off = ((unsigned)(sy * a.Win + sx) << (cin_shift + 1)) + (unsigned)(c8_fixed * 16);
-        R.v[i] = *reinterpret_cast<const u32x4_t*>(base + off);
-        R.ok = (R.ok & ~(1u << i)) | (ok ? (1u << i) : 0u);
+        cok = 0;
+#pragma unroll
+        for (int i = 0; i < C::IN_ITERS; ++i) {
+            int t2 = tid;
+            asm volatile("" : "+v"(t2));
+            const int p = (t2 + i * C::THREADS) >> 1;
+            const int py = p / W4_IW, px = p - py * W4_IW;
+            const int iy = oy1 + py, ix = ox1 + px;
+            const int WV = UPS ? a.Wout : a.Win;
+            const int cy = min(max(iy, a.iy_lo), a.iy_lo + a.iy_span - 1), cx = min(max(ix, 0), WV - 1);
+            const bool ok = iy == cy && ix == cx;
+            const int sy = (UPS ? (cy >> 1) : cy) + a.in_row_off, sx = UPS ? (cx >> 1) : cx;
+            coff[i] = ((unsigned)(sy * a.Win + sx) << (cin_shift + 1)) + (unsigned)(c8_fixed * 16);
+            cok |= ok ? (1u << i) : 0u;
+        }
+    };
+    auto load_chunk = [&](const StageInfo& si, int i, Regs& R) {       // si's item = the item item_offsets last saw
+        const char* base = reinterpret_cast<const char*>(a.in0) + (size_t)si.it.img * a.in_rows * a.Win * Cin * 2 + si.kc * 32;
+        R.v[i] = *reinterpret_cast<const u32x4_t*>(base + coff[i]);
+        R.ok = (R.ok & ~(1u << i)) | (cok & (1u << i));
     };
     auto load_stage = [&](const StageInfo& si, Regs& R) {
         R.ok = 0;
@@ -173,10 +183,12 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
     float cA[8], cB[8];
     auto stage_coeffs = [&](const float4& v) {          // publish to the wave's slot, read back this lane's half (c8)
         if constexpr (FUSED) {
-            if (lane < 8) reinterpret_cast<float4*>(coef_lds)[lane] = v;
+            // published as (A, A', B, B') per channel pair: a lane's float4 read is then the two register pairs the packed
+            // FMA takes (as (A, B, A', B') every use cost four moves to pair them up)
+            if (lane < 8) reinterpret_cast<float4*>(coef_lds)[lane] = make_float4(v.x, v.z, v.y, v.w);
             const float4* ab = reinterpret_cast<const float4*>(coef_lds + c8_fixed * 16);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float4 t = ab[e]; cA[2 * e] = t.x; cB[2 * e] = t.y; cA[2 * e + 1] = t.z; cB[2 * e + 1] = t.w; }
+            for (int e = 0; e < 4; ++e) { const float4 t = ab[e]; cA[2 * e] = t.x; cA[2 * e + 1] = t.y; cB[2 * e] = t.z; cB[2 * e + 1] = t.w; }
             if constexpr (FP8) {       // y' = kFp8ActScale * y: silu comes out pre-scaled for the e4m3 conversion at no per-element cost
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { cA[e] *= kFp8ActScale; cB[e] *= kFp8ActScale; }
@@ -375,8 +387,12 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
             if (st >= 4) {
                 const int i = st - 4;
                 if (!(DBG & 8) && i < C::IN_ITERS) {
-                    store_chunk(i, R, in_nxt);                           // stage s+1 input -> other tile
-                    load_chunk(sq2, i, R);                              // stage s+2 input -> R.v[i]
+                    // (the last chunk index only exists for the first threads: waves all of whose lanes are past the tile skip it)
+                    const bool live = (i + 1) * C::THREADS <= W4_IN_CHUNKS || __builtin_amdgcn_readfirstlane(wave) * 64 + i * C::THREADS < W4_IN_CHUNKS;
+                    if (live) {
+                        store_chunk(i, R, in_nxt);                       // stage s+1 input -> other tile
+                        load_chunk(sq2, i, R);                          // stage s+2 input -> R.v[i]
+                    }
                 }
                 if (FUSED && i == 0) cnext = fetch_coeffs(sq2);   // after the last use of the old coefficients (stage_coeffs at k-step 4)
                 // slab s+2: all DMA issues in k-steps 4 and 5, so that the stage's LAST VMEM operation is the third input chunk at
@@ -517,6 +533,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
         __syncthreads();          // stage barrier: buf[nxt] complete, buf[cur] free
         stamp(5);
         sq0 = sq1; sq1 = sq2; sq2 = cursor.next();
+        if (sq2.kc == 0) item_offsets(sq2.it);       // (past the queue's end the cursor stays on the last stage: kc != 0)
         widx = widx == 2 ? 0 : widx + 1;
         par ^= 1;
     };
@@ -529,6 +546,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
             float* sl = reinterpret_cast<float*>(smem + C::MAIN_BYTES + C::RED_BYTES + C::BIAS_BYTES + C::COEF_BYTES);
             if (tid < a.cout && tid < 256) sl[tid] = a.oscale[tid];
         }
+        item_offsets(sq0.it);        // stages 0, 1, 2 belong to one item (nkc >= 8)
         load_stage(sq0, R);
         if constexpr (FUSED) stage_coeffs(fetch_coeffs(sq0));
         const uint4* ws0 = reinterpret_cast<const uint4*>(wslab(sq0));
