@@ -26,7 +26,8 @@ SOURCES = [
     ("conv_down.hip", []),
     ("conv_f8.hip", []),
     ("conv_pc.hip", (["-DC3_ABL=" + os.environ["C3_ABL"]] if os.environ.get("C3_ABL") else []) +
-     (["-DC3_PRIO=" + os.environ["C3_PRIO"]] if os.environ.get("C3_PRIO") else [])),
+     (["-DC3_PRIO=" + os.environ["C3_PRIO"]] if os.environ.get("C3_PRIO") else []) +
+     (["-DC3_SCALAR=" + os.environ["C3_SCALAR"]] if os.environ.get("C3_SCALAR") else [])),
     ("gn.hip", []),
     ("fusion.hip", []),
     ("preprocess.hip", []),
@@ -34,8 +35,11 @@ SOURCES = [
     ("strips.cpp", []),
     ("api.cpp", []),
 ]
+# -fno-slp-vectorize: hipcc otherwise packs adjacent f32 adds / muls / FMAs into v_pk_*_f32, which beside MFMAs cost several
+# times two plain instructions (MI355X_MICROARCH.md per-instruction constants; measured: profiles/r02_experiments.md).
+# IRE_SLP=1 builds with the vectorizer on (A/B).
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-          "-D__HIP_PLATFORM_AMD__"]
+          "-D__HIP_PLATFORM_AMD__"] + ([] if os.environ.get("IRE_SLP") == "1" else ["-fno-slp-vectorize"])
 
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
@@ -57,14 +61,18 @@ def _deps_mtime():
 def _compile(src, extra, force, hdr_m):
     path = os.path.join(CSRC, src)
     obj = os.path.join(OBJ, src.replace(".", "_") + ".o")
-    if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(path)
-            and os.path.getmtime(obj) > hdr_m):
-        return obj
     lang = ["-x", "hip"] if src.endswith((".hip", ".cpp")) else []
     cmd = [_hipcc()] + COMMON + extra + lang + ["-c", path, "-o", obj]
+    stamp = obj + ".cmd"      # the command line the object was built with: a changed flag (build-time A/B macros) rebuilds it
+    same_cmd = os.path.exists(stamp) and open(stamp).read() == " ".join(cmd)
+    if (not force and same_cmd and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(path)
+            and os.path.getmtime(obj) > hdr_m):
+        return obj
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
+    with open(stamp, "w") as f:
+        f.write(" ".join(cmd))
     return obj
 
 

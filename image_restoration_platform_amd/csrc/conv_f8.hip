@@ -166,14 +166,11 @@ __global__ __launch_bounds__(F8_THREADS) void conv_f8_kernel(ConvArgs a) {
         int q[2] = {0, 0};
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const f32x2_t x = {f8_lo(wds[d]), f8_hi(wds[d])};
-            const f32x2_t A = {cA[2 * d], cA[2 * d + 1]}, B = {cB[2 * d], cB[2 * d + 1]};
-            const f32x2_t y = __builtin_elementwise_fma(x, A, B);
-            const f32x2_t t = y * (-1.4426950408889634f / kF8ActScale);
-            f32x2_t e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
-            e = e + 1.0f;
-            const f32x2_t rinv = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
-            const f32x2_t sv = y * rinv;
+            // plain f32 instructions (built with -fno-slp-vectorize): packed f32 is slower beside MFMAs, see conv_w4.hip
+            constexpr float K = -1.4426950408889634f / kF8ActScale;
+            const float y0 = __builtin_fmaf(f8_lo(wds[d]), cA[2 * d], cB[2 * d]), y1 = __builtin_fmaf(f8_hi(wds[d]), cA[2 * d + 1], cB[2 * d + 1]);
+            const float e0 = __builtin_amdgcn_exp2f(y0 * K) + 1.0f, e1 = __builtin_amdgcn_exp2f(y1 * K) + 1.0f;
+            const f32x2_t sv = {y0 * __builtin_amdgcn_rcpf(e0), y1 * __builtin_amdgcn_rcpf(e1)};
             const float f0 = __builtin_fminf(sv.x, 448.0f), f1 = __builtin_fminf(sv.y, 448.0f);
             q[d >> 1] = (d & 1) ? __builtin_amdgcn_cvt_pk_fp8_f32(f0, f1, q[d >> 1], true) : __builtin_amdgcn_cvt_pk_fp8_f32(f0, f1, q[d >> 1], false);
         }

@@ -31,6 +31,9 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
+#ifndef C3_SCALAR
+#define C3_SCALAR 1
+#endif
 #ifndef C3_PRIO
 #define C3_PRIO 1     // measured: priority 1 for the producer waves +0.5 % (911 -> 916 img/s); 3 the same
 #endif
@@ -203,6 +206,32 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
 #pragma unroll
                     for (int w = 0; w < 8; ++w) o[w] = wds[w];
                 } else {
+#if C3_SCALAR
+                    // plain f32 instructions, one channel each (build flag -fno-slp-vectorize keeps them so): beside the consumers'
+                    // MFMAs a packed f32 instruction costs several times two plain ones (MI355X_MICROARCH.md, per-instruction
+                    // constants; measured here: profiles/r02_experiments.md)
+                    float y[16], e[16];
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) {
+                        const int d = w & 3;
+                        y[2 * w] = __builtin_fmaf(c3_lo(wds[w]), cA[2 * d], cB[2 * d]);
+                        y[2 * w + 1] = __builtin_fmaf(c3_hi(wds[w]), cA[2 * d + 1], cB[2 * d + 1]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) e[k] = y[k] * (-1.4426950408889634f);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) e[k] = __builtin_amdgcn_exp2f(e[k]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) e[k] = e[k] + 1.0f;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) e[k] = __builtin_amdgcn_rcpf(e[k]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) o[w] = c3_pack(y[2 * w] * e[2 * w], y[2 * w + 1] * e[2 * w + 1]);
+#else
                     f32x2_t y[8], e[8];
 #pragma unroll
                     for (int w = 0; w < 8; ++w) {
@@ -225,6 +254,7 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int w = 0; w < 8; ++w) { const f32x2_t sv = y[w] * e[w]; o[w] = c3_pack(sv.x, sv.y); }
+#endif
                 }
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {

@@ -195,15 +195,14 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
             }
         }
     };
+    // (plain f32 instructions, one channel each, and the file is built with -fno-slp-vectorize: beside MFMAs a packed f32
+    // instruction costs several times two plain ones -- MI355X_MICROARCH.md per-instruction constants; profiles/r02_experiments.md)
     auto transform_pair = [&](unsigned w, int d) -> f32x2_t {        // (kFp8ActScale x) silu(x*A + B) of the word's two channels
-        const f32x2_t x = {w4_lo(w), w4_hi(w)};
-        const f32x2_t A = {cA[2 * d], cA[2 * d + 1]}, B = {cB[2 * d], cB[2 * d + 1]};
-        const f32x2_t y = __builtin_elementwise_fma(x, A, B);
-        const f32x2_t t = y * (FP8 ? -1.4426950408889634f / kFp8ActScale : -1.4426950408889634f);
-        f32x2_t e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
-        e = e + 1.0f;
-        const f32x2_t rinv = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
-        return y * rinv;
+        constexpr float K = FP8 ? -1.4426950408889634f / kFp8ActScale : -1.4426950408889634f;
+        const float y0 = __builtin_fmaf(w4_lo(w), cA[2 * d], cB[2 * d]), y1 = __builtin_fmaf(w4_hi(w), cA[2 * d + 1], cB[2 * d + 1]);
+        const float e0 = __builtin_amdgcn_exp2f(y0 * K) + 1.0f, e1 = __builtin_amdgcn_exp2f(y1 * K) + 1.0f;
+        const f32x2_t sv = {y0 * __builtin_amdgcn_rcpf(e0), y1 * __builtin_amdgcn_rcpf(e1)};
+        return sv;
     };
     auto transform_word = [&](unsigned w, int d) -> unsigned {
         const f32x2_t sv = transform_pair(w, d);
