@@ -650,7 +650,7 @@ void Engine::prof_begin(int fam, hipStream_t s, double flops, double bytes) {
     };
     // An event record is a packet of its own on the stream (~4 us between two kernels).  When the previous profiled launch's
     // end event is the stream's last operation, this launch starts its interval there: one event per boundary instead of two.
-    if (prof_chain_ && prof_chain_stream_ == s && !prof_.empty()) { r.e0 = prof_.back().e1; r.own_e0 = false; }
+    if (prof_chainable_ && prof_chain_ && prof_chain_stream_ == s && !prof_.empty()) { r.e0 = prof_.back().e1; r.own_e0 = false; }
     else { r.e0 = get(); IRE_HIP(hipEventRecord(r.e0, s)); }
     r.e1 = get();
     prof_.push_back(r);
@@ -948,7 +948,14 @@ void Engine::run_network(Lane& L, int nimg, int h, int w, const uint8_t* d_in, u
     Run R;
     R.stream = L.stream; R.stats = L.stats; R.stats_alt = L.stats2; R.ab = L.ab; R.film = d_film;
     const Geo g = geo_of_lane(L, nimg, h, w, d_in, d_out);
+    // inside one pass of the op list a profiled launch's end event is the next one's start (prof_begin): nothing but the
+    // engine's own wrapped launches goes onto the stream here.  Everywhere else (copies, host syncs between calls) records
+    // keep their own start event.
+    prof_chain_ = false;
+    prof_chainable_ = capture_ == false;
     for (const Op& op : program_) exec_op(R, op, g);
+    prof_chainable_ = false;
+    prof_chain_ = false;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -280,6 +280,7 @@ private:
     bool prof_open_ = false;
     bool prof_chain_ = false;          // the stream's last operation is prof_.back()'s end event (prof_chain_stream_): the next record starts there
     hipStream_t prof_chain_stream_ = nullptr;
+    bool prof_chainable_ = false;      // true while run_network walks the op list (the only place records may share events)
     std::vector<ProfRec> prof_;
     std::vector<hipEvent_t> ev_pool_;
     double prof_ms_[FAM_COUNT] = {}, prof_flops_[FAM_COUNT] = {}, prof_bytes_[FAM_COUNT] = {};

@@ -1,7 +1,7 @@
 # GPU box: the round's profile set -- default bench, kernel-trace stats, FETCH/WRITE PMC passes, utilisation PMC passes.
 # Every pass is its own run; --pmc is never combined with a trace domain.
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02_v3; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02_v4; mkdir -p $O
 cd $R
 timeout -k 10 300 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout -k 10 200 python bench.py --no-profile --no-cpu-baseline > $O/bench_noprofile.json 2>> $O/bench_default.err
