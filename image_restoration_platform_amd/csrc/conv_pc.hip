@@ -31,6 +31,9 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
+#ifndef C3_RES_PRE
+#define C3_RES_PRE 2
+#endif
 #ifndef C3_SCALAR
 #define C3_SCALAR 1
 #endif
@@ -341,6 +344,7 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
 
     f32x16_t acc[2][NTL];
     uint4 erv[2 * NTL][2];
+    constexpr int RES_PRE = C3_RES_PRE < 2 * NTL ? C3_RES_PRE : 2 * NTL;    // residual groups requested before the MFMAs; the rest after the k-loop
     unsigned eoffs[2];
     bool einb[2];
     unsigned hin[2] = {0u, 0u};           // head: this lane's dword of the two image rows
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int g = 0; g < 2 * NTL; ++g) erv[g][m] = *reinterpret_cast<const uint4*>(rbase + eoffs[m] + (unsigned)(g * 32));
+                    for (int g = 0; g < RES_PRE; ++g) erv[g][m] = *reinterpret_cast<const uint4*>(rbase + eoffs[m] + (unsigned)(g * 32));
             }
             if constexpr (HEAD) {
                 // the wave's two rows of the ORIGINAL image, 32 pixels = 96 contiguous bytes each: 24 dwords per row, requested
@@ -429,6 +433,16 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
             }
             ++stage_no;
             if (kc + 1 < NKC) { cs = cursor.next(); c3_barrier(); }      // the item's next stage: its tile is staged, this one is free
+        }
+        if constexpr (RESID && RES_PRE < 2 * NTL) {
+            // the rest of the residual rows: requested once the fragment registers are free (all of them before the MFMAs did not
+            // fit 168 registers: 18 were spilled, and a scratch reload in the k-loop waits, in order, for the residual rows first);
+            // the epilogue reaches them ~200 instructions later
+            const char* rbase = reinterpret_cast<const char*>(a.resid) + (size_t)it.img * a.Hout * a.Wout * (2 * C);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int g = RES_PRE; g < 2 * NTL; ++g) erv[g][m] = *reinterpret_cast<const uint4*>(rbase + eoffs[m] + (unsigned)(g * 32));
         }
         // ---- epilogue (conv_rb.hip's): accumulator i of n-tile j of lane (r, h) is cout 32 j + 16 (i >> 3) + 8 h + (i & 7) -----------
         if constexpr (HEAD) {
