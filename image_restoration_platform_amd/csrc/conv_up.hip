@@ -169,10 +169,14 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
             // ---- fused form: skip term by MFMA, bf16 stores, GroupNorm partials ------------------------------------------------
             constexpr int NKG = NKS / 2;              // units (two k-steps = 32 skip channels) per (parity, row)
             constexpr int U = 8 * NKG;                // unit u = (par * 2 + m) * NKG + kg
-#ifndef IRE_UP_D
-#define IRE_UP_D 4
+            // units in flight (2 x 16 B per lane each): as many as fit WITHOUT a spill -- a scratch reload in this epilogue queues
+            // behind the skip loads in flight (VMEM completes in order) and drains the ring.  Same-box A/B (IRE_UP_D = 4 / 3 / 2 for
+            // all): NKS 2: 337 / 362 / 342 us, NKS 4 (2 spills at 4): 259 / 253 / 270, NKS 8 (13 spills at 4, 5 at 3): 236 / 233 / 226
+#ifdef IRE_UP_D
+            constexpr int D = IRE_UP_D;
+#else
+            constexpr int D = NKS <= 2 ? 4 : NKS == 4 ? 3 : 2;
 #endif
-            constexpr int D = IRE_UP_D;               // units in flight: 2 x 16 B per lane each
             const int C = a.cout;
             const char* sbase = reinterpret_cast<const char*>(a.in1) + (size_t)it.img * a.Hout * a.Wout * C * 2;
             // loads past the image's last byte return zero; a pixel past the right edge reads a neighbour's bytes: either way the
