@@ -27,7 +27,6 @@ SOURCES = [
     ("conv_f8.hip", []),
     ("conv_pc.hip", (["-DC3_ABL=" + os.environ["C3_ABL"]] if os.environ.get("C3_ABL") else []) +
      (["-DC3_PRIO=" + os.environ["C3_PRIO"]] if os.environ.get("C3_PRIO") else []) +
-     (["-DC3_SCALAR=" + os.environ["C3_SCALAR"]] if os.environ.get("C3_SCALAR") else []) +
      (["-DC3_RES_PRE=" + os.environ["C3_RES_PRE"]] if os.environ.get("C3_RES_PRE") else [])),
     ("gn.hip", []),
     ("fusion.hip", []),
