@@ -10,8 +10,8 @@
 // materialised: staging simply reads row 2(Y0-1+py)+a, column 2(X0-1+px)+b of the NHWC tensor into a 17x33 halo tile, and
 // every fragment read is conv_rb.hip's conflict-free unit-stride pattern.
 //
-// Schedule: conv_rb.hip's (512-thread workgroup per CU, two LDS buffers, input register-prefetched two stages ahead, weights
-// by LDS-DMA, one barrier per stage).  Item = (16x32 OUTPUT tile, 64-cout block); a stage = 32 input channels of ONE phase
+// Schedule: conv_rb.hip's (512-thread workgroup per CU, two LDS input tiles, input register-prefetched two stages ahead, weights
+// by LDS-DMA two stages ahead into a ring of three slabs, one barrier per stage, counted waits: see `stage`).  Item = (16x32 OUTPUT tile, 64-cout block); a stage = 32 input channels of ONE phase
 // (4 * Cin/32 stages per item, 2 k-steps per tap).  Epilogue as the ResBlock convs': bias-initialised accumulators, bf16
 // stores straight from the accumulators (permuted slab rows), GroupNorm partial statistics per tile.
 // Roofline: input staging (the layer reads the full-resolution tensor: 4 staged pixels per output pixel), then MFMA.
@@ -36,9 +36,11 @@ constexpr int DN_IN_ITERS = (DN_IN_CHUNKS + DN_THREADS - 1) / DN_THREADS;    // 
 constexpr int DN_IN_BYTES = DN_IN_ITERS * DN_THREADS * 16;                   // 40960
 constexpr int DN_NT = 64, DN_NTL = 2;
 constexpr int DN_W_BYTES_MAX = 4 * 4 * DN_NT * 16;     // phase (1,1): 4 taps x 4 c8 x 64 rows x 16 B = 16 KB
-constexpr int DN_BUF = DN_IN_BYTES + DN_W_BYTES_MAX;
+constexpr int DN_W_BASE = 2 * DN_IN_BYTES;             // LDS: in[2] | w[3] | partial statistics | bias
+constexpr int DN_MAIN = DN_W_BASE + 3 * DN_W_BYTES_MAX;
 constexpr int DN_RED_HALF = 8 * (DN_NT / 8) * 4 * 4;
-constexpr int DN_LDS = 2 * DN_BUF + 2 * DN_RED_HALF + 256 * 4;
+constexpr int DN_LDS = DN_MAIN + 2 * DN_RED_HALF + 256 * 4;
+static_assert(DN_LDS <= 160 * 1024, "LDS");
 
 __device__ __forceinline__ unsigned dn_pack(float a, float b) {
     f32x2_t f = {a, b};
@@ -64,7 +66,13 @@ __host__ __device__ constexpr int dn_ntaps(int p) { return ((p >> 1) ? 2 : 1) * 
 __host__ __device__ constexpr int dn_slab_off(int p) { return p == 0 ? 0 : p == 1 ? 4096 : p == 2 ? 12288 : 20480; }   // bytes within a (nb, kc) group
 constexpr int DN_GROUP_BYTES = 9 * 4 * DN_NT * 16;      // 36 KB per (n-block, k-chunk): 9 taps
 
-struct DnRegs { uint4 v[DN_IN_ITERS]; };
+struct DnRegs { u32x4_t v[DN_IN_ITERS]; };
+__host__ __device__ constexpr int dn_dma_iters(int p) { return (dn_ntaps(p) * 4 * DN_NT + DN_THREADS - 1) / DN_THREADS; }   // LDS-DMA issues per wave for a phase's slab: 1, 1, 1, 2
+template <int N> __device__ __forceinline__ void dn_wait_vm(bool counted) {
+    // counted: at most N newer VMEM operations outstanding => everything issued before them is done (VMEM completes in order)
+    if (counted) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 
 __global__ __launch_bounds__(DN_THREADS) void conv_down_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[DN_LDS];
@@ -99,24 +107,44 @@ __global__ __launch_bounds__(DN_THREADS) void conv_down_kernel(ConvArgs a) {
         }
     const int b_off = (h * DN_NT + r) * 16;
 
-    // input of one stage: the (a, b) phase image of a 32-channel chunk, halo tile rows/cols -1 .. TH-1 / TW-1
-    auto load_stage = [&](const StageInfo& si, DnRegs& R) {
-        const PersistItem& it = si.it;
-        const int kc = si.kc >> 2, pa = (si.kc >> 1) & 1, pb = si.kc & 1;
-        const char* base = reinterpret_cast<const char*>(a.in0) + (size_t)it.img * a.in_rows * a.Win * Cin * 2 + kc * 64;
-        const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, a.in_rows * a.Win * Cin * 2 - kc * 64, 0x00020000);
-        const int y1 = 2 * (it.ty * DN_TH - 1) + pa, x1 = 2 * (it.tx * DN_TW - 1) + pb;    // full-res coordinates of tile pixel (0, 0)
+    // input of one stage: the (a, b) phase image of a 32-channel chunk, halo tile rows/cols -1 .. TH-1 / TW-1.
+    // A thread's chunks sit at the same tile positions in every stage of an item: their byte offsets (phase (0, 0)) and, per
+    // phase, whether they lie inside the image are computed once per ITEM (item_offsets, when the prefetch cursor sq2 enters a
+    // new item); a stage's request is then offset + the phase's scalar displacement, or out of range (reads as zero: the padding).
+    unsigned coff[DN_IN_ITERS], cokb = 0;         // cokb bit ph * DN_IN_ITERS + i
+    auto item_offsets = [&](const PersistItem& it) {
+        const int y0 = 2 * (it.ty * DN_TH - 1), x0 = 2 * (it.tx * DN_TW - 1);               // full-res coordinates of tile pixel (0, 0), phase (0, 0)
         int t2 = tid;
         asm volatile("" : "+v"(t2));
+        cokb = 0;
 #pragma unroll
         for (int i = 0; i < DN_IN_ITERS; ++i) {
             const int p = (t2 + i * DN_THREADS) >> 2;
             const int py = p / DN_IW, px = p - py * DN_IW;
-            const int iy = y1 + 2 * py, ix = x1 + 2 * px;
-            const bool ok = (unsigned)(iy - a.iy_lo) < (unsigned)a.iy_span && (unsigned)ix < (unsigned)a.Win;   // slots past the tile: harmless extra rows of the padded buffer
-            const unsigned off = ok ? ((unsigned)((iy + a.in_row_off) * a.Win + ix) << (cin_shift + 1)) + (unsigned)(c8_fixed * 16) : 0xffffffffu;
-            const u32x4_t lv = __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, 0);      // out of range reads as zero: the padding
-            R.v[i] = make_uint4(lv.x, lv.y, lv.z, lv.w);
+            const int iy = y0 + 2 * py, ix = x0 + 2 * px;
+            coff[i] = ((unsigned)((iy + a.in_row_off) * a.Win + ix) << (cin_shift + 1)) + (unsigned)(c8_fixed * 16);
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) {
+                const bool ok = (unsigned)(iy + (ph >> 1) - a.iy_lo) < (unsigned)a.iy_span && (unsigned)(ix + (ph & 1)) < (unsigned)a.Win;   // slots past the tile: harmless extra rows of the padded buffer
+                cokb |= ok ? (1u << (ph * DN_IN_ITERS + i)) : 0u;
+            }
+        }
+    };
+    auto load_stage = [&](const StageInfo& si, DnRegs& R) {          // si's item = the item item_offsets last saw
+        const PersistItem& it = si.it;
+        const int kc = si.kc >> 2, ph = si.kc & 3;
+        const char* base = reinterpret_cast<const char*>(a.in0) + (size_t)it.img * a.in_rows * a.Win * Cin * 2 + kc * 64;
+        // the requests are inline asm (hipcc then neither tracks nor waits for them: every wait in the stage loop is a counted
+        // s_waitcnt placed by hand, see `stage`); the resource descriptor by hand for the same reason
+        const unsigned long long ba = (unsigned long long)base;
+        u32x4_t irsrc = {(unsigned)ba, (unsigned)(ba >> 32) & 0xffffu, (unsigned)(a.in_rows * a.Win * Cin * 2 - kc * 64), 0x00020000u};
+        irsrc.x = __builtin_amdgcn_readfirstlane(irsrc.x); irsrc.y = __builtin_amdgcn_readfirstlane(irsrc.y); irsrc.z = __builtin_amdgcn_readfirstlane(irsrc.z);
+        const unsigned delta = (unsigned)((ph >> 1) * a.Win + (ph & 1)) << (cin_shift + 1);        // phase (a, b): a rows down, b pixels right
+        const unsigned okp = cokb >> (ph * DN_IN_ITERS);
+#pragma unroll
+        for (int i = 0; i < DN_IN_ITERS; ++i) {
+            const unsigned off = ((okp >> i) & 1u) ? coff[i] + delta : 0xffffffffu;
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "+v"(R.v[i]) : "v"(off), "s"(irsrc) : "memory");      // out of range reads as zero: the padding
         }
     };
     auto store_chunk = [&](int i, const DnRegs& R, uint4* lds_in) {
@@ -124,7 +152,7 @@ __global__ __launch_bounds__(DN_THREADS) void conv_down_kernel(ConvArgs a) {
         asm volatile("" : "+v"(t2));
         const int idx = t2 + i * DN_THREADS;
         const int p = idx >> 2;
-        lds_in[p * 4 + (c8_fixed ^ ((p >> 2) & 3))] = R.v[i];
+        reinterpret_cast<u32x4_t*>(lds_in)[p * 4 + (c8_fixed ^ ((p >> 2) & 3))] = R.v[i];
     };
     auto wslab = [&](const StageInfo& si) -> const unsigned char* {
         const int ph = si.kc & 3;
@@ -133,8 +161,8 @@ __global__ __launch_bounds__(DN_THREADS) void conv_down_kernel(ConvArgs a) {
     };
 
     f32x16_t acc[2][DN_NTL];
-    float* red_base = reinterpret_cast<float*>(smem + 2 * DN_BUF);       // 2 x [8 waves][8 chunks][4]
-    const float* bias_lds = reinterpret_cast<const float*>(smem + 2 * DN_BUF + 2 * DN_RED_HALF);
+    float* red_base = reinterpret_cast<float*>(smem + DN_MAIN);       // 2 x [8 waves][8 chunks][4]
+    const float* bias_lds = reinterpret_cast<const float*>(smem + DN_MAIN + 2 * DN_RED_HALF);
     int st_img = -1, st_tile = 0, st_nb = 0, st_par = 0, red_par = 0;
     auto flush_stats = [&]() {            // partials of the previous item: complete after the stage barrier
         if (st_img < 0) return;
@@ -225,34 +253,44 @@ __global__ __launch_bounds__(DN_THREADS) void conv_down_kernel(ConvArgs a) {
     };
 
     DnRegs R0, R1;
-    // ---- one stage: PHASE = a*2 + b of the stage's input (= stage index & 3; the LDS buffer is PHASE & 1) ----------------
+    int widx = 0;               // weight slab of the current stage (stage index % 3)
+    bool warm = false;          // false in the first stage after the prologue: its predecessors are the prologue's requests
+    // ---- one stage: PHASE = a*2 + b of the stage's input (= stage index & 3; the input tile is PHASE & 1) ----------------
+    // Pipeline (s = this stage).  A stage is short -- 8 to 32 MFMAs per wave, ~0.3-1 us -- so everything it consumes is
+    // requested TWO stages ahead: the input rows of s+2 into the free register set, the weight slab of s+2 by LDS-DMA into
+    // the third slab.  (With the slab requested one stage ahead and a vmcnt(0) per stage the kernel ran at one memory
+    // latency per stage: 157 / 131 us at levels 1 / 2 for 41 us of MFMA.)  All requests are inline asm, so every wait is a
+    // counted one placed here; VMEM order per stage and wave: 5 input requests, then D(phase + 2) slab pieces.
     auto stage = [&](auto phase_tag, auto last_tag) {
         constexpr int PHASE = decltype(phase_tag)::value, PAR = PHASE & 1;
         constexpr bool LAST = decltype(last_tag)::value;
         constexpr int PA = PHASE >> 1, PB = PHASE & 1, NTY = PA ? 2 : 1, NTX = PB ? 2 : 1, NTAPS = NTY * NTX;
-        const unsigned char* ib = smem + PAR * DN_BUF;
-        uint4* in_nxt = reinterpret_cast<uint4*>(smem + (PAR ^ 1) * DN_BUF);
-        const unsigned char* wb = smem + PAR * DN_BUF + DN_IN_BYTES + b_off;
-        unsigned char* w_nxt = smem + (PAR ^ 1) * DN_BUF + DN_IN_BYTES;
-        DnRegs& Rn = PAR ? R0 : R1;   // holds stage s+1 (loaded during stage s-1)
+        constexpr int D1 = dn_dma_iters((PHASE + 1) & 3), D2 = dn_dma_iters((PHASE + 2) & 3);   // slab pieces requested in stage s-1, s
+        const unsigned char* ib = smem + PAR * DN_IN_BYTES;
+        uint4* in_nxt = reinterpret_cast<uint4*>(smem + (PAR ^ 1) * DN_IN_BYTES);
+        const unsigned char* wb = smem + DN_W_BASE + widx * DN_W_BYTES_MAX + b_off;
+        const int w2 = widx == 0 ? 2 : widx - 1;         // (s + 2) % 3
+        DnRegs& Rn = PAR ? R0 : R1;   // holds stage s+1 (requested at the start of stage s-1)
         DnRegs& Rf = PAR ? R1 : R0;   // free: receives stage s+2
-#pragma unroll
-        for (int i = 0; i < DN_IN_ITERS; ++i) asm volatile("" : "+v"(Rn.v[i].x), "+v"(Rn.v[i].y), "+v"(Rn.v[i].z), "+v"(Rn.v[i].w));
         load_stage(sq2, Rf);
-        {   // weight slab of stage s+1 (phase (PHASE+1)&3: 4, 8, 8 or 16 KB) by LDS-DMA into the other buffer; branch-free: a wave
-            // past the slab's end re-fetches a 64-piece group another wave also fetches (same bytes, same destination)
-            constexpr int NPH = (PHASE + 1) & 3;
+        {   // weight slab of stage s+2 (phase (PHASE+2)&3: 4, 8, 8 or 16 KB) by LDS-DMA; branch-free: a wave past the slab's end
+            // re-fetches a 64-piece group another wave also fetches (same bytes, same destination)
+            constexpr int NPH = (PHASE + 2) & 3;
             constexpr int pieces = dn_ntaps(NPH) * 4 * DN_NT;           // 16-B pieces: 256, 512, 512, 1024
-            const unsigned char* ws = wslab(sq1);
+            const unsigned char* ws = wslab(sq2);
             const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-            const unsigned w_nxt_lds = smem_lds + (unsigned)(w_nxt - smem);
+            const unsigned w_dst_lds = smem_lds + (unsigned)(DN_W_BASE + w2 * DN_W_BYTES_MAX);
 #pragma unroll
-            for (int i = 0; i < (pieces + DN_THREADS - 1) / DN_THREADS; ++i) {
+            for (int i = 0; i < D2; ++i) {
                 int cbase = i * DN_THREADS + wave_u * 64;
                 if ((i + 1) * DN_THREADS > pieces) cbase = cbase % pieces;
-                dn_glds16(ws + (size_t)(cbase + lane) * 16, w_nxt_lds + cbase * 16);
+                dn_glds16(ws + (size_t)(cbase + lane) * 16, w_dst_lds + cbase * 16);
             }
         }
+        // the rows of stage s+1: requested at the start of stage s-1; since then: that stage's slab pieces, this stage's requests
+        dn_wait_vm<DN_IN_ITERS + D1 + D2>(warm);
+#pragma unroll
+        for (int i = 0; i < DN_IN_ITERS; ++i) asm volatile("" : "+v"(Rn.v[i]));
         // NTAPS taps x 2 channel pairs; tap t = ty*NTX + tx reads tile offset (dy, dx): dy = PA ? ty - 1 : 0, dx = PB ? tx - 1 : 0
         constexpr int NG = NTAPS * 2;
         bf16x8_t afr[2][2], bfr[2][DN_NTL];
@@ -280,24 +318,31 @@ __global__ __launch_bounds__(DN_THREADS) void conv_down_kernel(ConvArgs a) {
             for (int i = g * per; i < (g + 1) * per && i < DN_IN_ITERS; ++i) store_chunk(i, Rn, in_nxt);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // retire the s+2 prefetch (oldest in the in-order VMEM queue), then the DMA'd slab, before the stage barrier
-#pragma unroll
-        for (int i = 0; i < DN_IN_ITERS; ++i) asm volatile("" : "+v"(Rf.v[i].x), "+v"(Rf.v[i].y), "+v"(Rf.v[i].z), "+v"(Rf.v[i].w));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the slab of stage s+1 (requested during stage s-1) is in LDS before the barrier; newer: this stage's requests
+        dn_wait_vm<DN_IN_ITERS + D2>(warm);
+        warm = true;
         if constexpr (LAST) epilogue(sq0.it);
         __syncthreads();
         flush_stats();
         sq0 = sq1; sq1 = sq2; sq2 = cursor.next();
+        if (sq2.kc == 0) item_offsets(sq2.it);       // (past the queue's end the cursor stays on the last stage: kc != 0)
+        widx = widx == 2 ? 0 : widx + 1;
     };
 
     // ---- prologue: stage 0 (phase 0) -> LDS buffer 0, stage 1 -> registers --------------------------------------------------
     {
-        float* bl = reinterpret_cast<float*>(smem + 2 * DN_BUF + 2 * DN_RED_HALF);
+        float* bl = reinterpret_cast<float*>(smem + DN_MAIN + 2 * DN_RED_HALF);
         if (tid < a.cout && tid < 256) bl[tid] = a.bias[tid];
+        item_offsets(sq0.it);        // stages 0, 1, 2 belong to one item (an item has 4 * nkc >= 4 stages)
         load_stage(sq0, R0);
-        const uint4* ws = reinterpret_cast<const uint4*>(wslab(sq0));
-        uint4* wd = reinterpret_cast<uint4*>(smem + DN_IN_BYTES);
-        for (int i = tid; i < dn_ntaps(0) * 4 * DN_NT; i += DN_THREADS) wd[i] = ws[i];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < DN_IN_ITERS; ++i) asm volatile("" : "+v"(R0.v[i]));
+        const uint4* ws0 = reinterpret_cast<const uint4*>(wslab(sq0));
+        const uint4* ws1 = reinterpret_cast<const uint4*>(wslab(sq1));
+        uint4* wd = reinterpret_cast<uint4*>(smem + DN_W_BASE);
+        for (int i = tid; i < dn_ntaps(0) * 4 * DN_NT; i += DN_THREADS) wd[i] = ws0[i];                            // slab of stage 0 -> slot 0
+        for (int i = tid; i < dn_ntaps(1) * 4 * DN_NT; i += DN_THREADS) wd[DN_W_BYTES_MAX / 16 + i] = ws1[i];      // stage 1 -> slot 1
         uint4* in0 = reinterpret_cast<uint4*>(smem);
 #pragma unroll
         for (int i = 0; i < DN_IN_ITERS; ++i) store_chunk(i, R0, in0);
