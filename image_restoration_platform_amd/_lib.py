@@ -44,6 +44,7 @@ SYMBOLS = {
     "ire_classify_device": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ire_restore_device": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ire_fuse_device": (_i, [_vp, _vp, _i, _i, _i, ctypes.c_double, _vp, _vp, _vp]),
+    "ire_fuse_batch_device": (_i, [_vp, _vp, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_double), _vp, _vp, _vp]),
     "ire_preprocess_plan": (_i, [_i, _i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "ire_preprocess": (_i, [_vp, _u8p, _i, _i, _i, _i, _u8p, _i, _i]),
     "ire_preprocess_device": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),

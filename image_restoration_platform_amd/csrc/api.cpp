@@ -340,6 +340,14 @@ int ire_fuse_device(ire_engine* e, const uint8_t* d_rgb_views, int k, int h, int
     });
 }
 
+int ire_fuse_batch_device(ire_engine* e, const uint8_t* d_rgb_views, int nsets, int k, int h, int w, const double* noise_scores,
+                          uint8_t* d_out_rgb, int32_t* d_shifts, void* stream) {
+    return guarded([&] {
+        Engine& E = eng(e);
+        on_stream(E, (hipStream_t)stream, [&] { fuse_batch_device(E, d_rgb_views, nsets, k, h, w, noise_scores, d_out_rgb, d_shifts, (hipStream_t)stream); });
+    });
+}
+
 int ire_preprocess_plan(int width, int height, int orientation, int max_dim, int* out_w, int* out_h, int* resized) {
     return guarded([&] {
         if (!out_w || !out_h) fail(IRE_ERR_INVALID_INPUT, "invalid arguments to ire_preprocess_plan");

@@ -158,7 +158,7 @@ Engine::~Engine() {
     for (void* p : net_.allocs) (void)hipFree(p);
     for (void* p : table_allocs_) (void)hipFree(p);
     for (void* p : {(void*)d_in_, (void*)d_out_, (void*)d_jpeg_, (void*)d_sums_, (void*)d_scores_, (void*)d_label_,
-                    (void*)d_cond_, (void*)d_film_, (void*)d_fL_, (void*)d_fQ_, (void*)d_fsad_, (void*)d_fmisc_, (void*)d_pp_tab_, (void*)d_pp_mid_, (void*)d_pp_in_, (void*)d_pp_out_})
+                    (void*)d_cond_, (void*)d_film_, (void*)d_fL_, (void*)d_fQ_, (void*)d_fsad_, (void*)d_fmisc_, (void*)d_fwlut_, (void*)d_pp_tab_, (void*)d_pp_mid_, (void*)d_pp_in_, (void*)d_pp_out_})
         if (p) (void)hipFree(p);
     for (auto& L : lanes_) {
         if (L.stream) (void)hipStreamDestroy(L.stream);

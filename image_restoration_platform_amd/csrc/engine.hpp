@@ -139,7 +139,7 @@ public:
                         const uint8_t* d_is_jpeg, uint8_t* d_out, hipStream_t stream);
 
     // fusion (fusion.hip)
-    void fuse_launch(const uint8_t* d_views, int k, int h, int w, const unsigned* host_wlut, uint8_t* d_out,
+    void fuse_launch(const uint8_t* d_views, int nsets, int k, int h, int w, const unsigned* host_wluts, uint8_t* d_out,
                      int32_t* d_shifts, hipStream_t s);
     double noise_of_view0(const uint8_t* d_views, int h, int w, hipStream_t s);
     void fuse_host_impl(const uint8_t* rgb_views, int k, int h, int w, double noise_score, uint8_t* out_rgb,
@@ -247,6 +247,8 @@ private:
     int last_n_ = 0;
     // fusion scratch
     size_t fuse_cap_px_ = 0;
+    int fuse_cap_sets_ = 0;
+    unsigned* d_fwlut_ = nullptr;
     uint8_t* d_fL_ = nullptr;
     uint8_t* d_fQ_ = nullptr;
     unsigned* d_fsad_ = nullptr;

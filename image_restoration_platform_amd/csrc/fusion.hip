@@ -39,6 +39,8 @@ __global__ void fusion_luma_kernel(const uint8_t* __restrict__ rgb, int k, int H
     const int Hq = H >> 2, Wq = W >> 2;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= k * Hq * Wq) return;
+    const size_t set = blockIdx.y;                       // view set of a batched call: its own views, luma planes, quarter planes
+    rgb += set * (size_t)k * H * W * 3; L += set * (size_t)3 * H * W; Q += set * (size_t)3 * Hq * qp;
     const int v = i / (Hq * Wq), rem = i - v * Hq * Wq;
     const int yq = rem / Wq, xq = rem - yq * Wq;
     unsigned sum = 0;
@@ -96,6 +98,14 @@ __global__ __launch_bounds__(256) void fusion_sad_kernel(const uint8_t* __restri
     __shared__ int s_last;
     const int tid = threadIdx.x;
     const int v = blockIdx.y + 1;
+    {   // view set blockIdx.z of a batched call: its own planes, shifts, partial rows and ticket
+        const size_t set = blockIdx.z;
+        P += set * (size_t)3 * PH * pitch;
+        coarse += set * 6; shifts += set * 6;
+        if (shifts_out) shifts_out += set * 2 * k;
+        part += set * (size_t)2 * FUSE_SAD_GRID * NC;
+        ticket += set;
+    }
     for (int i = tid; i < 2 * N; i += 256) (&s_sad[0][0])[i] = 0;
     const int by = MODE == 0 ? 0 : 4 * coarse[v * 2], bx = MODE == 0 ? 0 : 4 * coarse[v * 2 + 1];
     const uint8_t* P0 = P;
@@ -224,9 +234,11 @@ struct FuseWlut { unsigned w[256]; };   // the blend weights ride in the kernel 
 
 __global__ __launch_bounds__(256) void fusion_blend_kernel(const uint8_t* __restrict__ rgb, int k, int H, int W,
                                                            const int* __restrict__ shifts,
-                                                           const FuseWlut wlut, uint8_t* __restrict__ out) {
+                                                           const FuseWlut wlut, const unsigned* __restrict__ wluts, uint8_t* __restrict__ out) {
     __shared__ unsigned s_w[256];
-    s_w[threadIdx.x] = wlut.w[threadIdx.x];
+    const size_t set = blockIdx.y;                       // view set of a batched call; its blend table comes from `wluts` (one call: kernel arguments)
+    s_w[threadIdx.x] = wluts ? wluts[set * 256 + threadIdx.x] : wlut.w[threadIdx.x];
+    rgb += set * (size_t)k * H * W * 3; out += set * (size_t)H * W * 3; shifts += set * 6;
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= H * W) return;
@@ -271,38 +283,49 @@ void check_fuse_args(int k, int h, int w) {
 
 }  // namespace
 
-void Engine::fuse_launch(const uint8_t* d_views, int k, int h, int w, const unsigned* host_wlut, uint8_t* d_out,
+void Engine::fuse_launch(const uint8_t* d_views, int nsets, int k, int h, int w, const unsigned* host_wluts, uint8_t* d_out,
                          int32_t* d_shifts, hipStream_t s) {
     const size_t px = (size_t)h * w;
     const int hq = h / 4, wq = w / 4, qp = (wq + 3) & ~3;
-    if (fuse_cap_px_ < px) {
+    if (fuse_cap_px_ < px || fuse_cap_sets_ < nsets) {
         IRE_HIP(hipDeviceSynchronize());
-        for (void* p : {(void*)d_fL_, (void*)d_fQ_, (void*)d_fsad_, (void*)d_fmisc_}) if (p) (void)hipFree(p);
-        d_fL_ = (uint8_t*)dalloc(3 * px);
-        d_fQ_ = (uint8_t*)dalloc(3 * ((size_t)h / 4) * (((size_t)w / 4 + 3) & ~(size_t)3) + 64);   // pitch: a multiple of 4
-        d_fsad_ = (unsigned*)dalloc(sizeof(unsigned) * 2 * FUSE_SAD_GRID * NC);   // per-workgroup SAD rows (coarse and fine take turns)
-        d_fmisc_ = (int*)dalloc(sizeof(int) * (6 + 6 + 4));   // coarse[3][2], shifts[3][2], ticket
-        IRE_HIP(hipMemsetAsync(d_fmisc_, 0, sizeof(int) * (6 + 6 + 4), s));   // the ticket starts at zero; the kernels reset it
-        fuse_cap_px_ = px;
+        for (void* p : {(void*)d_fL_, (void*)d_fQ_, (void*)d_fsad_, (void*)d_fmisc_, (void*)d_fwlut_}) if (p) (void)hipFree(p);
+        const size_t cpx = std::max(px, fuse_cap_px_);
+        const int cs = std::max(nsets, fuse_cap_sets_);
+        // per view set: 3 luma planes, 3 quarter-res planes (pitch: a multiple of 4),
+        // per-workgroup SAD rows (coarse and fine take turns), coarse[3][2] + shifts[3][2], a ticket, a blend table
+        d_fL_ = (uint8_t*)dalloc((size_t)cs * 3 * cpx);
+        d_fQ_ = (uint8_t*)dalloc((size_t)cs * 3 * (cpx / 16 + cpx / 64 + 16) + 64);      // (w >= 64: the pitch adds at most 3 to a row of >= 16)
+        d_fsad_ = (unsigned*)dalloc(sizeof(unsigned) * (size_t)cs * 2 * FUSE_SAD_GRID * NC);
+        d_fmisc_ = (int*)dalloc(sizeof(int) * (size_t)cs * 16);
+        d_fwlut_ = (unsigned*)dalloc(sizeof(unsigned) * (size_t)cs * 256);
+        IRE_HIP(hipMemsetAsync(d_fmisc_, 0, sizeof(int) * (size_t)cs * 16, s));   // the tickets start at zero; the kernels reset them
+        fuse_cap_px_ = cpx; fuse_cap_sets_ = cs;
     }
+    // d_fmisc_: [sets][6] coarse | [sets][6] shifts | [sets] tickets
     int* d_coarse = d_fmisc_;
-    int* d_sh = d_fmisc_ + 6;
-    unsigned* d_ticket = reinterpret_cast<unsigned*>(d_fmisc_ + 12);
+    int* d_sh = d_fmisc_ + 6 * fuse_cap_sets_;
+    unsigned* d_ticket = reinterpret_cast<unsigned*>(d_fmisc_ + 12 * fuse_cap_sets_);
     FuseWlut lut;
-    std::memcpy(lut.w, host_wlut, sizeof(lut.w));
-    prof_begin(FAM_FUSION, s, 0, (double)(k + 1) * px * 3);
+    std::memcpy(lut.w, host_wluts, sizeof(lut.w));
+    prof_begin(FAM_FUSION, s, 0, (double)nsets * (k + 1) * px * 3);
+    const unsigned* d_wluts = nullptr;
+    if (nsets > 1) {      // one table per set (its own noise score); a single call carries its table in the kernel arguments
+        IRE_HIP(hipMemcpyAsync(d_fwlut_, host_wluts, sizeof(unsigned) * 256 * nsets, hipMemcpyHostToDevice, s));   // pageable source: staged before the call returns
+        d_wluts = d_fwlut_;
+    }
     const int nq = k * hq * wq;
-    hipLaunchKernelGGL(fusion_luma_kernel, dim3(ceil_div(nq, 256)), dim3(256), 0, s, d_views, k, h, w, qp, d_fL_, d_fQ_);
+    hipLaunchKernelGGL(fusion_luma_kernel, dim3(ceil_div(nq, 256), nsets), dim3(256), 0, s, d_views, k, h, w, qp, d_fL_, d_fQ_);
     auto tiles = [](int ph, int pw, int m, int step, int tw, int sr) {
         return ceil_div(pw - 2 * m, tw) * ceil_div(ceil_div(ph - 2 * m, step), sr);
     };
     const int g0 = std::min(FUSE_SAD_GRID, tiles(hq, wq, CR, 1, SadCfg<0>::TW, SadCfg<0>::SR));
     const int g1 = std::min(FUSE_SAD_GRID, tiles(h, w, FM, 2, SadCfg<1>::TW, SadCfg<1>::SR));
-    hipLaunchKernelGGL(fusion_sad_kernel<0>, dim3(g0, k - 1), dim3(256), 0, s, d_fQ_, k, hq, wq, qp, d_coarse, d_sh, (int*)nullptr,
+    hipLaunchKernelGGL(fusion_sad_kernel<0>, dim3(g0, k - 1, nsets), dim3(256), 0, s, d_fQ_, k, hq, wq, qp, d_coarse, d_sh, (int*)nullptr,
                        d_fsad_, d_ticket);
-    hipLaunchKernelGGL(fusion_sad_kernel<1>, dim3(g1, k - 1), dim3(256), 0, s, d_fL_, k, h, w, w, d_coarse, d_sh, (int*)d_shifts,
+    hipLaunchKernelGGL(fusion_sad_kernel<1>, dim3(g1, k - 1, nsets), dim3(256), 0, s, d_fL_, k, h, w, w, d_coarse, d_sh, (int*)d_shifts,
                        d_fsad_, d_ticket);
-    hipLaunchKernelGGL(fusion_blend_kernel, dim3(ceil_div((int)px, 256)), dim3(256), 0, s, d_views, k, h, w, d_sh, lut, d_out);
+    hipLaunchKernelGGL(fusion_blend_kernel, dim3(ceil_div((int)px, 256), nsets), dim3(256), 0, s, d_views, k, h, w, d_sh, lut, d_wluts, d_out);
     IRE_HIP(hipGetLastError());
     prof_end(s);
 }
@@ -318,12 +341,24 @@ double Engine::noise_of_view0(const uint8_t* d_views, int h, int w, hipStream_t 
 
 void fuse_device(Engine& E, const uint8_t* d_rgb_views, int k, int h, int w, double noise_score, uint8_t* d_out_rgb,
                  int32_t* d_shifts, hipStream_t stream) {
+    fuse_batch_device(E, d_rgb_views, 1, k, h, w, &noise_score, d_out_rgb, d_shifts, stream);
+}
+
+// `nsets` independent view sets in one call: d_rgb_views [nsets][k][h][w][3], noise_scores [nsets] on the HOST (< 0: classify
+// view 0 of that set), d_out_rgb [nsets][h][w][3], d_shifts [nsets][k][2] or null.  Every kernel of the chain takes the set as
+// a grid dimension, so a batch costs the chain's four dependent launches once.
+void fuse_batch_device(Engine& E, const uint8_t* d_rgb_views, int nsets, int k, int h, int w, const double* noise_scores,
+                       uint8_t* d_out_rgb, int32_t* d_shifts, hipStream_t stream) {
     check_fuse_args(k, h, w);
-    if (!d_rgb_views || !d_out_rgb) fail(IRE_ERR_INVALID_INPUT, "invalid input: null image pointer");
-    if (noise_score < 0) noise_score = E.noise_of_view0(d_rgb_views, h, w, stream);
-    unsigned lut[256];
-    make_wlut(noise_score, lut);
-    E.fuse_launch(d_rgb_views, k, h, w, lut, d_out_rgb, d_shifts, stream);
+    if (nsets < 1 || nsets > kFuseMaxSets) fail(IRE_ERR_INVALID_INPUT, "invalid batch size for fusion: expected 1..16 view sets");
+    if (!d_rgb_views || !d_out_rgb || !noise_scores) fail(IRE_ERR_INVALID_INPUT, "invalid input: null pointer");
+    std::vector<unsigned> luts((size_t)nsets * 256);
+    for (int i = 0; i < nsets; ++i) {
+        double ns = noise_scores[i];
+        if (ns < 0) ns = E.noise_of_view0(d_rgb_views + (size_t)i * k * h * w * 3, h, w, stream);
+        make_wlut(ns, luts.data() + (size_t)i * 256);
+    }
+    E.fuse_launch(d_rgb_views, nsets, k, h, w, luts.data(), d_out_rgb, d_shifts, stream);
 }
 
 void fuse_host(Engine& E, const uint8_t* rgb_views, int k, int h, int w, double noise_score, uint8_t* out_rgb,
@@ -345,10 +380,10 @@ void Engine::fuse_host_impl(const uint8_t* rgb_views, int k, int h, int w, doubl
     IRE_HIP(hipEventRecord(ev_[2], s));
     unsigned lut[256];
     make_wlut(noise_score, lut);
-    fuse_launch(d_in_, k, h, w, lut, d_out_, nullptr, s);
+    fuse_launch(d_in_, 1, k, h, w, lut, d_out_, nullptr, s);
     IRE_HIP(hipEventRecord(ev_[3], s));
     IRE_HIP(hipMemcpyAsync(out_rgb, d_out_, px * 3, hipMemcpyDeviceToHost, s));
-    if (shifts_out) IRE_HIP(hipMemcpyAsync(shifts_out, d_fmisc_ + 6, sizeof(int) * 2 * k, hipMemcpyDeviceToHost, s));
+    if (shifts_out) IRE_HIP(hipMemcpyAsync(shifts_out, d_fmisc_ + 6 * fuse_cap_sets_, sizeof(int) * 2 * k, hipMemcpyDeviceToHost, s));
     IRE_HIP(hipStreamSynchronize(s));
     if (t) {
         float a = 0, b = 0, c = 0;

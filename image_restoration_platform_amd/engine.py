@@ -215,6 +215,20 @@ class Engine:
                                               self._stream_ptr(stream)))
         return out, shifts
 
+    def fuse_batch_tensor(self, views_u8, noise_scores=None, stream=None):
+        """views [B,k,H,W,3] uint8 on the GPU (B <= 16 view sets of one shape) -> (fused [B,H,W,3], shifts [B,k,2]).
+        noise_scores: B floats (host), each < 0 / None => classify view 0 of that set inside.  One pass of the kernel chain."""
+        import torch
+        assert views_u8.is_cuda and views_u8.dtype == torch.uint8 and views_u8.is_contiguous() and views_u8.dim() == 5
+        b, k, h, w, _ = views_u8.shape
+        ns = (ctypes.c_double * b)(*([-1.0] * b if noise_scores is None else [float(x) for x in noise_scores]))
+        out = torch.empty((b, h, w, 3), dtype=torch.uint8, device=views_u8.device)
+        shifts = torch.zeros((b, k, 2), dtype=torch.int32, device=views_u8.device)
+        self._check(self._lib.ire_fuse_batch_device(self._h, ctypes.c_void_p(views_u8.data_ptr()), b, k, h, w, ns,
+                                                    ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(shifts.data_ptr()),
+                                                    self._stream_ptr(stream)))
+        return out, shifts
+
     # ---- cfg 4: row strips ----------------------------------------------------------------------
     def restore_tiled_tensor(self, rgb_u8, nstrips, out_u8=None, scores=None, is_jpeg_u8=None, stream=None):
         """One [H,W,3] image restored as `nstrips` row strips on this GPU (virtual ranks: per-level halo exchange and the

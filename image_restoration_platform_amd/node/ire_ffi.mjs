@@ -25,6 +25,7 @@ export function bindIre(libPath) {
     ire_classify_device: ['int', [P, P, 'int', 'int', 'int', P, P, P, P]],
     ire_restore_device: ['int', [P, P, 'int', 'int', 'int', P, P, P, P]],
     ire_fuse_device: ['int', [P, P, 'int', 'int', 'int', 'double', P, P, P]],
+    ire_fuse_batch_device: ['int', [P, P, 'int', 'int', 'int', 'int', P, P, P, P]],
     ire_preprocess_plan: ['int', ['int', 'int', 'int', 'int', IP, IP, IP]],
     ire_preprocess: ['int', [P, P, 'int', 'int', 'int', 'int', P, 'int', 'int']],
     ire_preprocess_device: ['int', [P, P, 'int', 'int', 'int', 'int', P, 'int', 'int', P]],

@@ -121,6 +121,12 @@ int ire_restore_device(ire_engine* e, const uint8_t* d_rgb, int n, int h, int w,
                        uint8_t* d_out_rgb, void* stream);
 int ire_fuse_device(ire_engine* e, const uint8_t* d_rgb_views, int k, int h, int w, double noise_score,
                     uint8_t* d_out_rgb, int32_t* d_shifts, void* stream);
+/* Several restoreImage() calls with 2..3 images each (geminiClient.js:32,49), coalesced like the batcher coalesces single-image
+ * jobs: nsets (1..16) independent view sets of one shape in one call -- d_rgb_views [nsets][k][h][w][3], d_out_rgb
+ * [nsets][h][w][3], d_shifts [nsets][k][2] (may be NULL), noise_scores [nsets] doubles in HOST memory (each < 0 => classify
+ * view 0 of that set inside).  Results are those of nsets ire_fuse_device calls; the kernel chain runs once. */
+int ire_fuse_batch_device(ire_engine* e, const uint8_t* d_rgb_views, int nsets, int k, int h, int w,
+                          const double* noise_scores, uint8_t* d_out_rgb, int32_t* d_shifts, void* stream);
 
 /* ---- preprocess step in front of the path (server-node/src/middleware/imagePreprocess.js:24-91) ---- */
 /* Pixel part of preprocessImage(): EXIF auto-orient (:43) and fit-inside-max_dim Lanczos-3 resize (:46-55); the JPEG
