@@ -39,7 +39,8 @@ SOURCES = [
 # times two plain instructions (MI355X_MICROARCH.md per-instruction constants; measured: profiles/r02_experiments.md).
 # IRE_SLP=1 builds with the vectorizer on (A/B).
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-          "-D__HIP_PLATFORM_AMD__"] + ([] if os.environ.get("IRE_SLP") == "1" else ["-fno-slp-vectorize"])
+          "-D__HIP_PLATFORM_AMD__"] + ([] if os.environ.get("IRE_SLP") == "1" else ["-fno-slp-vectorize"]) + \
+         os.environ.get("IRE_XFLAGS", "").split()          # extra compiler flags for build-time A/B (tools/s2_xflags.sh)
 
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
