@@ -79,6 +79,18 @@ def test_end_to_end_vs_fp32_oracle(engine, weights0, h, w, n):
     assert np.abs(out.astype(np.int32) - imgs.astype(np.int32)).mean() > 1.0     # not the identity
 
 
+def test_seeded_random_shapes_vs_fp32_oracle(engine, weights0):
+    """Shapes nobody picked by hand (heights / widths = random multiples of 8 in 16..176, 1..3 images): tile grids with 1..6 x 1..6
+    tiles at level 0, ragged at every level, items of one workgroup crossing image boundaries -- the per-item offset caches of
+    conv_w4 / conv_down and the producers' tile-local bounds see every combination of border flags."""
+    rng = np.random.default_rng(20261004)
+    for _ in range(6):
+        h, w, n = int(rng.integers(2, 23)) * 8, int(rng.integers(2, 23)) * 8, int(rng.integers(1, 4))
+        imgs = synth.batch(n, h, w, start=int(rng.integers(0, 50)))
+        sc = _scores(imgs)
+        _assert_close(engine.restore(imgs, scores=sc), onet.restore(imgs, sc, weights0))
+
+
 @pytest.mark.parametrize("env", [{"IRE_W4": "0"}, {"IRE_W4_WAVES": "4", "IRE_ACT_SPLIT_MINC": "128"}, {"IRE_W4_WAVES": "4"}, {"IRE_CONV_V1": "1"}, {"IRE_UP_RB_MINC": "64"},
                                  {"IRE_ACT_SPLIT_MINC": "64"}, {"IRE_ACT_SPLIT_MINC": "128"}, {"IRE_UP_SUBPIX": "0"}, {"IRE_UP_FUSE": "0"}, {"IRE_GN_FOLD": "0"}, {"IRE_PC": "0"}, {"IRE_PC": "1"}, {"IRE_PC": "7"}, {"IRE_PC": "3"}, {"IRE_PC": "0", "IRE_GN_FOLD": "0"}, {"IRE_DOWN_RB": "0", "IRE_HEAD_RB": "0"},
                                  {"IRE_W4_FUSED_MINC": "100000", "IRE_ACT_SPLIT_MINC": "256"}, {"IRE_W4_FUSED_MINC": "100000"}])
