@@ -126,7 +126,8 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
     if (__builtin_amdgcn_readfirstlane(wave) >= 8) {
         // =============================== producers: waves 8..11 ===============================================================
 #if C3_PRIO
-        asm volatile("s_setprio %0" :: "n"(C3_PRIO));            // the producers are the youngest waves of their SIMD: without this they issue in the consumers' leftover slots
+        // (C = 32 ResBlock convs: the producers at the consumers' priority is faster -- RB1 278 -> 267 us; the head and C = 64 want them above)
+        if (C3_PRIO != 1 || C != 32 || HEAD) asm volatile("s_setprio %0" :: "n"(C3_PRIO));            // the producers are the youngest waves of their SIMD: without this they issue in the consumers' leftover slots
 #endif
         const int tp = tid - C3_CONS;
         const int c8 = tp & 3;                                   // this thread always stages the same 8-channel slice of a pixel

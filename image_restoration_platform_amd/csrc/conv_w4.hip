@@ -354,9 +354,11 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
             // progress feedback: a wave early in its stage outranks one that is further along.  (The SIMD's arbitration otherwise
             // favours the older of its two waves: it runs ahead, idles ~a quarter of every stage at the barrier, and the younger
             // one then runs without a partner to fill its stalls -- tools/s2_stamps.sh.  A static priority only swaps the roles.)
+            // (boundaries 0 / 4 / 7 -- the MFMA-only k-steps, the first three staging k-steps, the last two -- measured against 0 / 3 / 6:
+            //  RB1 / RB2 168.2 / 191.1 -> 165.0 / 187.2 us; 0 / 5 / 7 and 0 / 4 / 8 the same as 0 / 4 / 7)
             if (WAVES == 8 && st == 0) __builtin_amdgcn_s_setprio(3);
-            if (WAVES == 8 && st == 3) __builtin_amdgcn_s_setprio(2);
-            if (WAVES == 8 && st == 6) __builtin_amdgcn_s_setprio(1);
+            if (WAVES == 8 && st == 4) __builtin_amdgcn_s_setprio(2);
+            if (WAVES == 8 && st == 7) __builtin_amdgcn_s_setprio(1);
             if (st + 1 < W4_NSTEPS && !(DBG & 2)) read_frags(st + 1, bfr[(st + 1) & 1], afr[(st + 1) & 1]);
             if (st == 4) {
                 // everything issued during the previous stage (R loads, slab s+1, epilogue stores) has had >= 4 k-steps
