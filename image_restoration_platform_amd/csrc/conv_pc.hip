@@ -407,8 +407,15 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
         // NKC stages of 18 k-steps (tap, channel half): two pixel fragments + NTL weight fragments, read one k-step ahead
 #pragma unroll NKC <= 2 ? NKC : 1
         for (int kc = 0; kc < NKC; ++kc) {
-            const unsigned char* ib = smem + (stage_no & 1) * C3_IN_BYTES;
-            const unsigned char* wk = wb + (K::STREAM ? (stage_no & 1) : kc) * K::W_STAGE;
+          // PAR: the stage's LDS tile as a compile-time constant where that pays (the head: two copies of the k-loop under a
+          // wave-uniform branch on the item's parity, 219 -> 205 us; C = 64: the unrolled stage index) -- the tile base then rides in
+          // the ds_read offset field instead of one v_add per fragment address (24 per item).  Run-time (-1) for the C = 32
+          // ResBlock convs (two copies measured 3 us slower there) and the streamed forms
+          auto stage_body = [&](auto par_tag) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_tag)::value;
+            const int par = PAR >= 0 ? PAR : (stage_no & 1);
+            const unsigned char* ib = smem + par * C3_IN_BYTES;
+            const unsigned char* wk = wb + (K::STREAM ? par : kc) * K::W_STAGE;
             bf16x8_t af[2][2], bf[2][NTL];
             auto read_k = [&](int g, bf16x8_t (&pa)[2], bf16x8_t (&pw)[NTL]) __attribute__((always_inline)) {
                 const int tap = g >> 1, cp = g & 1;
@@ -432,6 +439,10 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
+          };
+            if constexpr (NKC == 1 && HEAD) { if (stage_no & 1) stage_body(std::integral_constant<int, 1>{}); else stage_body(std::integral_constant<int, 0>{}); }
+            else if constexpr (NKC == 2) { if (kc & 1) stage_body(std::integral_constant<int, 1>{}); else stage_body(std::integral_constant<int, 0>{}); }   // (an item starts on an even stage)
+            else stage_body(std::integral_constant<int, -1>{});
             ++stage_no;
             if (kc + 1 < NKC) { cs = cursor.next(); c3_barrier(); }      // the item's next stage: its tile is staged, this one is free
         }
