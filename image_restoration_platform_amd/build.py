@@ -65,7 +65,8 @@ def _compile(src, extra, force, hdr_m):
     lang = ["-x", "hip"] if src.endswith((".hip", ".cpp")) else []
     cmd = [_hipcc()] + COMMON + extra + lang + ["-c", path, "-o", obj]
     stamp = obj + ".cmd"      # the command line the object was built with: a changed flag (build-time A/B macros) rebuilds it
-    same_cmd = os.path.exists(stamp) and open(stamp).read() == " ".join(cmd)
+    cmd_id = " ".join(cmd).replace(HERE, "<pkg>")      # (location-independent: the tree is built here and used on the GPU box)
+    same_cmd = os.path.exists(stamp) and open(stamp).read() == cmd_id
     if (not force and same_cmd and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(path)
             and os.path.getmtime(obj) > hdr_m):
         return obj
@@ -73,7 +74,7 @@ def _compile(src, extra, force, hdr_m):
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
     with open(stamp, "w") as f:
-        f.write(" ".join(cmd))
+        f.write(cmd_id)
     return obj
 
 
