@@ -24,6 +24,7 @@ SOURCES = [
     ("conv_up.hip", (["-DIRE_UP_ABL=" + os.environ["IRE_UP_ABL"]] if os.environ.get("IRE_UP_ABL") else []) +
      (["-DIRE_UP_D=" + os.environ["IRE_UP_D"]] if os.environ.get("IRE_UP_D") else [])),
     ("conv_down.hip", []),
+    ("conv_stem.hip", []),
     ("conv_f8.hip", []),
     ("conv_pc.hip", (["-DC3_ABL=" + os.environ["C3_ABL"]] if os.environ.get("C3_ABL") else []) +
      (["-DC3_PRIO=" + os.environ["C3_PRIO"]] if os.environ.get("C3_PRIO") else []) +

@@ -77,6 +77,7 @@ void conv_w4_launch(bool resid, const ConvArgs& a, hipStream_t stream);
 void conv_f8_launch(bool resid, const ConvArgs& a, hipStream_t stream);
 // CONV_DOWN on the pipelined schedule (conv_down.hip): the stride-2 conv as a unit-stride conv over the four pixel phases.
 // a.Hin/Win = full-res source, a.Hout/Wout = half; a.nkc = Cin/32, a.nblocks = cout/64, tiles of 16x32 OUTPUT pixels.
+void conv_stem_launch(const ConvArgs& a, hipStream_t stream);            // conv_stem.hip: u8 RGB -> 32 channels
 void conv_down_launch(const ConvArgs& a, hipStream_t stream);
 // CONV_HEAD through the pipelined kernel (conv_rb.hip, HEAD variant): a.w = permuted-row slab (32 rows, 3 used), 16x32 tiles.
 void conv_head_launch(const ConvArgs& a, hipStream_t stream);

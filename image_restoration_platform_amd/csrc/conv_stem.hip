@@ -1,0 +1,190 @@
+// conv_stem.hip -- RestoreNet-v0's first layer (u8 RGB -> 32 channels, 3x3) as a kernel of its own, gfx950.
+//
+// K = 3 x 3 x 3 = 27: one 16x32-pixel tile of u8 input is 1.8 KB and the whole layer is two MFMAs per 32 pixels, so the
+// kernel is its output stream (64 B per pixel: 537 MB per 8 x 1024^2) plus a small epilogue.  The v1 template (conv_mfma.hip)
+// padded the 3 channels to 8 and ran the generic 9-tap schedule: 177 us; this kernel 150 us (181 before the next tile's bytes were
+// requested ahead).  An ideal fill of the output's size takes 84 us.
+//
+//   * a workgroup (512 threads) stages a tile's 18 x 34 x 3 bytes as bf16 (u8 -> bf16 is exact) in LDS, zero outside the image;
+//     the bytes of the NEXT tile are requested before this tile's arithmetic (four per thread, in registers)
+//   * a wave owns two pixel rows: per row two K = 16 steps of `v_mfma_f32_32x32x16_bf16`, couts on rows (permuted like every
+//     other slab: a lane owns 8 contiguous couts), k = ky*9 + kx*3 + c, k >= 27 reads a zero
+//   * the B fragment of lane (pixel r, half h), step ks is k = 16 ks + 8 h .. + 8: elements of up to two tile rows, gathered
+//     with 16-bit LDS reads from per-lane offsets computed once per kernel
+//   * epilogue as conv_pc's: accumulators start at the bias, bf16 stores straight from the accumulators, GroupNorm partial
+//     statistics (8 groups of 4 channels) of the stored values per tile
+#include "conv_mfma.hpp"
+
+namespace ire {
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int ST_THREADS = 512, ST_TH = 16, ST_TW = 32, ST_IH = ST_TH + 2, ST_IW = ST_TW + 2;
+constexpr int ST_RB = ST_IW * 3;            // bytes (= elements) of a tile row: 102
+constexpr int ST_ROW = 104;                 // LDS row pitch in bf16 elements
+constexpr int ST_ZERO = ST_IH * ST_ROW;     // an element that is always zero (k >= 27)
+constexpr int ST_ITERS = (ST_IH * ST_RB + ST_THREADS - 1) / ST_THREADS;     // 4 bytes per thread and tile
+
+__device__ __forceinline__ unsigned st_pack(float a, float b) {
+    f32x2_t f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_t));
+}
+template <int N> __device__ __forceinline__ float st_ror_add(float v) {
+    const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false);
+    return v + __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ float st_swap16_add(float v) {
+    float x = v, y = v;
+    asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return x + y;
+}
+
+// two workgroups per CU (119 registers): they overlap one another's staging, arithmetic and stores; three would need <= 80
+// registers (36 spilled: 289 us against 150)
+__global__ __launch_bounds__(ST_THREADS) void conv_stem_kernel(ConvArgs a) {
+    __shared__ unsigned short tile[2][ST_IH * ST_ROW + 8];
+    __shared__ float red[2][8][8][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+
+    // A fragments (weights): [ks][h][32 permuted rows][8] bf16, engine.cpp::make_conv (d_wstem)
+    const u32x4_t* wf = reinterpret_cast<const u32x4_t*>(a.w);
+    const bf16x8_t w0 = __builtin_bit_cast(bf16x8_t, wf[(0 * 2 + h) * 32 + r]);
+    const bf16x8_t w1 = __builtin_bit_cast(bf16x8_t, wf[(1 * 2 + h) * 32 + r]);
+    // accumulator i of lane-half h is cout 16 (i >> 3) + 8 h + (i & 7) (permuted slab rows)
+    f32x16_t bias_acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bias_acc[i] = a.bias[16 * (i >> 3) + 8 * h + (i & 7)];
+    // element offsets of this lane's B fragments relative to (first tile row of the output row) * ST_ROW + 3 r
+    int koff[2][8];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 16 * ks + 8 * h + e, ky = k / 9, rem = k - ky * 9;
+            koff[ks][e] = k < 27 ? ky * ST_ROW + rem : -1;
+        }
+    if (tid < 8) { tile[0][ST_ZERO + tid] = 0; tile[1][ST_ZERO + tid] = 0; }
+    // this thread's bytes of a tile: element i = tid + 512 it -> (row py, byte b of the row): the same for every tile
+    int spy[ST_ITERS], sb[ST_ITERS];
+#pragma unroll
+    for (int it = 0; it < ST_ITERS; ++it) {
+        const int i = tid + it * ST_THREADS;
+        spy[it] = i / ST_RB; sb[it] = i - spy[it] * ST_RB;
+    }
+
+    const int tiles_per_img = a.tiles_x * a.tiles_y, total = tiles_per_img * a.nimg;
+    const unsigned char* in = reinterpret_cast<const unsigned char*>(a.in0);
+    const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+    unsigned pv[ST_ITERS];
+    auto request = [&](int item) {                  // the tile's bytes -> pv (zero outside the image)
+        const int img = item / tiles_per_img, t = item - img * tiles_per_img;
+        const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+#pragma unroll
+        for (int it = 0; it < ST_ITERS; ++it) {
+            const int py = spy[it], b = sb[it], px = b / 3;
+            const int iy = ty * ST_TH - 1 + py, ix = tx * ST_TW - 1 + px;
+            const bool ok = py < ST_IH && (unsigned)(iy - a.iy_lo) < (unsigned)a.iy_span && (unsigned)ix < (unsigned)a.Win;
+            const size_t off = (((size_t)img * a.in_rows + (ok ? iy : a.iy_lo) + a.in_row_off) * a.Win + (ok ? ix : 0)) * 3 + (b - px * 3);
+            const unsigned v = in[off];
+            pv[it] = ok ? v : 0u;
+        }
+    };
+    int par = 0;
+    if ((int)blockIdx.x < total) request(blockIdx.x);
+    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+        const int img = item / tiles_per_img, t = item - img * tiles_per_img;
+        const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+        unsigned short* tl = tile[par];
+#pragma unroll
+        for (int it = 0; it < ST_ITERS; ++it)
+            if (spy[it] < ST_IH) tl[spy[it] * ST_ROW + sb[it]] = (unsigned short)(__builtin_bit_cast(unsigned, (float)pv[it]) >> 16);      // u8 -> bf16: exact
+        if (item + (int)gridDim.x < total) request(item + gridDim.x);      // in flight across this tile's arithmetic and stores
+        __syncthreads();                               // tile[par] is staged (its previous readers passed the barrier of the tile before last)
+        // ---- per pixel row: two MFMAs, then stores + GroupNorm partials (groups of 4 channels: a lane's 8 contiguous couts are two groups) ----
+        const int ox = tx * ST_TW + r;
+        char* obase = reinterpret_cast<char*>(a.out) + (size_t)img * a.Hout * a.Wout * 64;
+        float gs[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gq[2][2] = {{0.f, 0.f}, {0.f, 0.f}};      // [pp][half of the 8 couts]
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int base = (2 * wave + m) * ST_ROW + 3 * r;
+            u32x4_t f[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int o0 = koff[ks][2 * d], o1 = koff[ks][2 * d + 1];
+                    const unsigned lo = tl[o0 >= 0 ? base + o0 : ST_ZERO], hi = tl[o1 >= 0 ? base + o1 : ST_ZERO];
+                    f[ks][d] = lo | (hi << 16);
+                }
+            f32x16_t c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, __builtin_bit_cast(bf16x8_t, f[0]), bias_acc, 0, 0, 0);     // D[cout][pixel]
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, __builtin_bit_cast(bf16x8_t, f[1]), c, 0, 0, 0);
+            const int oy = ty * ST_TH + 2 * wave + m;
+            const bool inb = ox < a.Wout && oy < a.Hout;
+            const float mf = inb ? 1.f : 0.f;
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const unsigned w[4] = {st_pack(c[8 * pp + 0], c[8 * pp + 1]), st_pack(c[8 * pp + 2], c[8 * pp + 3]),
+                                       st_pack(c[8 * pp + 4], c[8 * pp + 5]), st_pack(c[8 * pp + 6], c[8 * pp + 7])};
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const bf16x2_t wv = __builtin_bit_cast(bf16x2_t, w[d]);
+                    const float s1 = __builtin_amdgcn_fdot2_f32_bf16(wv, ones, 0.f, false), q1 = __builtin_amdgcn_fdot2_f32_bf16(wv, wv, 0.f, false);
+                    gs[pp][d >> 1] = __builtin_fmaf(s1, mf, gs[pp][d >> 1]);
+                    gq[pp][d >> 1] = __builtin_fmaf(q1, mf, gq[pp][d >> 1]);
+                }
+                if (inb) {
+                    const u32x4_t wv4 = {w[0], w[1], w[2], w[3]};
+                    *reinterpret_cast<u32x4_t*>(obase + ((size_t)oy * a.Wout + ox) * 64 + (16 * pp + 8 * h) * 2) = wv4;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);         // one row's accumulators live at a time
+        }
+        if (a.stats) {
+            // sum over the 32 lanes of each half (the 32 pixels of the wave's rows); group of (pp, half) = 4 pp + 2 h + half
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    float s = gs[pp][hf], q = gq[pp][hf];
+                    s = st_ror_add<1>(s); q = st_ror_add<1>(q);
+                    s = st_ror_add<2>(s); q = st_ror_add<2>(q);
+                    s = st_ror_add<4>(s); q = st_ror_add<4>(q);
+                    s = st_ror_add<8>(s); q = st_ror_add<8>(q);
+                    s = st_swap16_add(s); q = st_swap16_add(q);
+                    if (r == 0) { red[par][wave][4 * pp + 2 * h + hf][0] = s; red[par][wave][4 * pp + 2 * h + hf][1] = q; }
+                }
+            __syncthreads();                           // (also: every wave is done with tile[par] long before it is staged again, two tiles on)
+            if (tid < 8) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) { s += red[par][w][tid][0]; q += red[par][w][tid][1]; }
+                float* st = a.stats + (((size_t)img * tiles_per_img + t) * 8 + tid) * 2;
+                st[0] = s; st[1] = q;
+            }
+        }
+        par ^= 1;
+    }
+}
+
+}  // namespace
+
+// a.in0 = u8 [nimg][in_rows][Win][3] (rows iy_lo .. iy_lo + iy_span readable, the rest zero), a.out = bf16 [nimg][Hout][Wout][32],
+// a.w = A fragments [2][2][32][8] bf16 (engine.cpp::make_conv), a.bias[32], a.stats partials [img][tile][8][2]; 16x32 tiles
+void conv_stem_launch(const ConvArgs& a, hipStream_t stream) {
+    if (a.cout != 32 || a.Hout != a.Hin || a.Wout != a.Win || !a.stats) fail(IRE_ERR_INTERNAL, "internal: conv_stem shape");
+    const int items = a.tiles_x * a.tiles_y * a.nimg;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int grid = items < 2 * cus ? items : 2 * cus;
+    hipLaunchKernelGGL(conv_stem_kernel, dim3(grid), dim3(ST_THREADS), 0, stream, a);
+    IRE_HIP(hipGetLastError());
+}
+
+}  // namespace ire

@@ -95,6 +95,7 @@ Engine::Engine(const ire_config& cfg) {
     if (const char* v = std::getenv("IRE_PC")) pc_split_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_HEAD_RB")) head_rb_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_DOWN_RB")) down_rb_ = std::atoi(v);
+    if (const char* v = std::getenv("IRE_STEM_RB")) stem_rb_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_FP8_MX")) fp8_mx_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_RB_STAMPS")) {   // diagnostic: "<cout>[r]" = stamp the first such ResBlock conv
         stamps_cout_ = std::atoi(v);
@@ -239,6 +240,22 @@ ConvW Engine::make_conv(ConvKind kind, const std::string& wname, const std::stri
         c.d_wp = (unsigned short*)dalloc(arrp.size() * 2);
         net_.allocs.push_back(c.d_wp);
         IRE_HIP(hipMemcpy(c.d_wp, arrp.data(), arrp.size() * 2, hipMemcpyHostToDevice));
+    }
+    if (kind == CONV_STEM && cin == 3 && cout == 32) {
+        // conv_stem.hip: lane (row rho, half h) of k-step ks holds W[perm(rho)][k = 16 ks + 8 h + e], k = ky*9 + kx*3 + c, zero from 27
+        std::vector<unsigned short> arrs(2 * 2 * 32 * 8, 0);
+        for (int ks = 0; ks < 2; ++ks)
+            for (int hh = 0; hh < 2; ++hh)
+                for (int rho = 0; rho < 32; ++rho)
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = 16 * ks + 8 * hh + e;
+                        if (k >= 27) continue;
+                        const int ky = k / 9, rem = k % 9, kx = rem / 3, ch = rem % 3;
+                        arrs[(((size_t)ks * 2 + hh) * 32 + rho) * 8 + e] = f32_to_bf16(W[((size_t)perm(rho) * cin + ch) * 9 + ky * 3 + kx]);
+                    }
+        c.d_wstem = (unsigned short*)dalloc(arrs.size() * 2);
+        net_.allocs.push_back(c.d_wstem);
+        IRE_HIP(hipMemcpy(c.d_wstem, arrs.data(), arrs.size() * 2, hipMemcpyHostToDevice));
     }
     if (kind == CONV_DOWN && cin % 32 == 0 && cout % 64 == 0) {
         // conv_down.hip: the stride-2 conv as a unit-stride conv over the four pixel phases P_ab[Y][X] = in[2Y+a][2X+b]:
@@ -819,7 +836,8 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     const bool up_fused = up_sub && op.in1 != BUF_NONE;                     // composed with the 1x1 `fuse` (build_program)
     const bool head_rb = cw.kind == CONV_HEAD && rb_tile_h_ == kRbTileH && head_rb_ && cw.d_wp != nullptr;    // the head on the pipelined kernel
     const bool down_rb = cw.kind == CONV_DOWN && rb_tile_h_ == kRbTileH && down_rb_ && cw.d_wd != nullptr;    // stride-2 convs by pixel phase
-    const int th = (rb || up_rb || head_rb || down_rb) ? rb_tile_h_ : conv_tile_h(cw.kind);
+    const bool stem_rb = cw.kind == CONV_STEM && rb_tile_h_ == kRbTileH && stem_rb_ && cw.d_wstem != nullptr && op.stats_out;  // the stem on its own kernel
+    const int th = (rb || up_rb || head_rb || down_rb || stem_rb) ? rb_tile_h_ : conv_tile_h(cw.kind);
     a.tiles_y = ceil_div(Hout, th);
     if (up_sub) {
         a.tiles_x = ceil_div(Win, 32); a.tiles_y = ceil_div(Hin, 16);
@@ -888,6 +906,7 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
         conv_w4_launch(cw.kind == CONV_RB2, a, R.stream);
     } else if (head_rb) { a.w = cw.d_wp; if (pc_split_ & 1) conv_pc_launch(false, true, a, R.stream); else conv_head_launch(a, R.stream); }
     else if (down_rb) { a.w = cw.d_wd; a.nkc = cw.cin / 32; a.nblocks = cw.cout / 64; conv_down_launch(a, R.stream); }
+    else if (stem_rb) { a.w = cw.d_wstem; conv_stem_launch(a, R.stream); }
     else if (up_fused) {
         a.w = cw.d_wuf; a.w1 = cw.d_wsk; a.bias = cw.d_bias_uf; a.nkc = cw.cin / 32; a.nblocks = cw.cout / 32;
         a.in1 = in_ptr(op.in1) + (size_t)g.halo * Wout * cw.cout;      // the skip tensor is read at output pixels only: first real row

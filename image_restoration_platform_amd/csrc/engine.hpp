@@ -29,6 +29,7 @@ struct ConvW {
     unsigned short* d_w = nullptr;
     unsigned short* d_wp = nullptr;   // slabs with permuted cout rows for conv_rb.hip's direct epilogue
     unsigned short* d_w4 = nullptr;  // second arrangement for conv_w4.hip (C >= 128 ResBlock convs): 16-channel stages, 128-cout blocks
+    unsigned short* d_wstem = nullptr;  // CONV_STEM as MFMA A fragments (conv_stem.hip): [ks 2][h 2][32 permuted rows][8], k = ky*9 + kx*3 + c (27 of 32)
     unsigned short* d_wd = nullptr;  // CONV_DOWN by pixel phase (conv_down.hip): [nblock64][kc32][phase: 1+2+2+4 taps][tap*4 + c8][64][8]
     unsigned short* d_wu = nullptr;  // CONV_UP as a sub-pixel conv (conv_up.hip): [nblock32][kc32][parity][kk][32][8], taps pre-summed per parity
     // CONV_UP composed with the level's 1x1 `fuse` (engine.cpp::make_up_fused; conv_up.hip fused form)
@@ -213,6 +214,7 @@ private:
     int head_rb_ = 1;             // the 32 -> 3 head conv on conv_rb.hip's pipelined kernel (IRE_HEAD_RB=0: the v1 kernel)
     int pc_split_ = 3;            // producer / consumer workgroups (conv_pc.hip): bit 0 = C = 32 ResBlock convs + head, bit 1 = C = 64, bit 2 = C >= 128 on 64-cout items (slower than conv_w4.hip: 205 vs 190 us per launch, off by default); IRE_PC=0: conv_rb.hip / conv_w4.hip
     int gn_fold_ = 1;             // GroupNorm finalize inside the consuming conv's prologue (gn_fold.hpp); IRE_GN_FOLD=0: 33 gn_finalize launches per step
+    int stem_rb_ = 1;             // the stem on its own kernel (conv_stem.hip); IRE_STEM_RB=0: the v1 template
     int up_fuse_ = 1;             // `up` + 1x1 `fuse` as ONE composed convolution with the skip term in conv_up.hip's epilogue (IRE_UP_FUSE=0: two kernels)
     int up_subpixel_ = 1;         // `up` convs as sub-pixel convolutions on the low-res grid (IRE_UP_SUBPIX=0: nearest x2 + 3x3 on conv_rb.hip)
     int up_rb_min_c_ = 32;        // `up` convs with cout >= this run on conv_rb.hip (IRE_UP_RB_MINC), the rest on the v1 kernel
