@@ -48,7 +48,7 @@ __device__ __forceinline__ float st_swap16_add(float v) {
 // two workgroups per CU (119 registers): they overlap one another's staging, arithmetic and stores; three would need <= 80
 // registers (36 spilled: 289 us against 150)
 __global__ __launch_bounds__(ST_THREADS) void conv_stem_kernel(ConvArgs a) {
-    __shared__ unsigned short tile[2][ST_IH * ST_ROW + 8];
+    __shared__ unsigned short tile[2][ST_IH * ST_ROW + ST_ROW + 8];       // + zero elements at ST_ZERO and ST_ZERO + ST_ROW (k >= 27, rows m = 0 / 1)
     __shared__ float red[2][8][8][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
 
@@ -61,21 +61,23 @@ __global__ __launch_bounds__(ST_THREADS) void conv_stem_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) bias_acc[i] = a.bias[16 * (i >> 3) + 8 * h + (i & 7)];
     // element offsets of this lane's B fragments relative to (first tile row of the output row) * ST_ROW + 3 r
-    int koff[2][8];
+    int koff[2][8];                                  // element index within a tile for this wave's row m = 0 (m = 1: + ST_ROW)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = 16 * ks + 8 * h + e, ky = k / 9, rem = k - ky * 9;
-            koff[ks][e] = k < 27 ? ky * ST_ROW + rem : -1;
+            koff[ks][e] = k < 27 ? (2 * wave + ky) * ST_ROW + 3 * r + rem : ST_ZERO;
         }
-    if (tid < 8) { tile[0][ST_ZERO + tid] = 0; tile[1][ST_ZERO + tid] = 0; }
+    if (tid < ST_ROW + 8) { tile[0][ST_ZERO + tid] = 0; tile[1][ST_ZERO + tid] = 0; }
     // this thread's bytes of a tile: element i = tid + 512 it -> (row py, byte b of the row): the same for every tile
-    int spy[ST_ITERS], sb[ST_ITERS];
+    int spy[ST_ITERS], sb[ST_ITERS], spx[ST_ITERS], srel[ST_ITERS];
 #pragma unroll
     for (int it = 0; it < ST_ITERS; ++it) {
         const int i = tid + it * ST_THREADS;
         spy[it] = i / ST_RB; sb[it] = i - spy[it] * ST_RB;
+        spx[it] = sb[it] / 3;
+        srel[it] = (spy[it] * a.Win + spx[it]) * 3 + (sb[it] - spx[it] * 3);        // byte offset from the tile's first halo pixel
     }
 
     const int tiles_per_img = a.tiles_x * a.tiles_y, total = tiles_per_img * a.nimg;
@@ -85,13 +87,12 @@ __global__ __launch_bounds__(ST_THREADS) void conv_stem_kernel(ConvArgs a) {
     auto request = [&](int item) {                  // the tile's bytes -> pv (zero outside the image)
         const int img = item / tiles_per_img, t = item - img * tiles_per_img;
         const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+        const int iy0 = ty * ST_TH - 1, ix0 = tx * ST_TW - 1;
+        const long long base = (((long long)img * a.in_rows + iy0 + a.in_row_off) * a.Win + ix0) * 3;      // (may point before the buffer: only used where ok)
 #pragma unroll
         for (int it = 0; it < ST_ITERS; ++it) {
-            const int py = spy[it], b = sb[it], px = b / 3;
-            const int iy = ty * ST_TH - 1 + py, ix = tx * ST_TW - 1 + px;
-            const bool ok = py < ST_IH && (unsigned)(iy - a.iy_lo) < (unsigned)a.iy_span && (unsigned)ix < (unsigned)a.Win;
-            const size_t off = (((size_t)img * a.in_rows + (ok ? iy : a.iy_lo) + a.in_row_off) * a.Win + (ok ? ix : 0)) * 3 + (b - px * 3);
-            const unsigned v = in[off];
+            const bool ok = spy[it] < ST_IH && (unsigned)(iy0 + spy[it] - a.iy_lo) < (unsigned)a.iy_span && (unsigned)(ix0 + spx[it]) < (unsigned)a.Win;
+            const unsigned v = in[ok ? base + srel[it] : 0];
             pv[it] = ok ? v : 0u;
         }
     };
@@ -112,14 +113,12 @@ __global__ __launch_bounds__(ST_THREADS) void conv_stem_kernel(ConvArgs a) {
         float gs[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gq[2][2] = {{0.f, 0.f}, {0.f, 0.f}};      // [pp][half of the 8 couts]
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            const int base = (2 * wave + m) * ST_ROW + 3 * r;
             u32x4_t f[2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    const int o0 = koff[ks][2 * d], o1 = koff[ks][2 * d + 1];
-                    const unsigned lo = tl[o0 >= 0 ? base + o0 : ST_ZERO], hi = tl[o1 >= 0 ? base + o1 : ST_ZERO];
+                    const unsigned lo = tl[koff[ks][2 * d] + m * ST_ROW], hi = tl[koff[ks][2 * d + 1] + m * ST_ROW];
                     f[ks][d] = lo | (hi << 16);
                 }
             f32x16_t c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, __builtin_bit_cast(bf16x8_t, f[0]), bias_acc, 0, 0, 0);     // D[cout][pixel]
