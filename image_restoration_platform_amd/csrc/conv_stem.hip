@@ -15,6 +15,8 @@
 //     statistics (8 groups of 4 channels) of the stored values per tile
 #include "conv_mfma.hpp"
 
+#include <type_traits>
+
 namespace ire {
 
 namespace {
@@ -145,19 +147,29 @@ __global__ __launch_bounds__(ST_THREADS) void conv_stem_kernel(ConvArgs a) {
             __builtin_amdgcn_sched_barrier(0);         // one row's accumulators live at a time
         }
         if (a.stats) {
-            // sum over the 32 lanes of each half (the 32 pixels of the wave's rows); group of (pp, half) = 4 pp + 2 h + half
+            // Sum of the 8 values (4 groups x (sum, squares)) over the 32 lanes of a half, TRANSPOSING for the first two steps as
+            // conv_pc.hip does: a lane keeps half of its values and hands the other half to its partner (lane ^ 1, then lane ^ 2), so
+            // 8 -> 4 -> 2 values per lane; those take the plain steps over lane bits 2, 3 and 4.  Value index v = 2 pp + hf: group
+            // 4 pp + 2 h + hf.  Lane l of a half ends with (kind = b0) of the values 2 b1 and 2 b1 + 1, i.e. pp = b1, hf = 0 / 1.
+            const bool b0 = lane & 1, b1 = lane & 2;
+            auto xch = [&](float keep, float give, auto ctrl_tag) __attribute__((always_inline)) -> float {
+                const int gg = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), decltype(ctrl_tag)::value, 0xf, 0xf, false);
+                return keep + __builtin_bit_cast(float, gg);
+            };
+            const float vs[4] = {gs[0][0], gs[0][1], gs[1][0], gs[1][1]}, vq[4] = {gq[0][0], gq[0][1], gq[1][0], gq[1][1]};
+            float u[4], t2[2];
 #pragma unroll
-            for (int pp = 0; pp < 2; ++pp)
+            for (int k = 0; k < 4; ++k) u[k] = xch(b0 ? vq[k] : vs[k], b0 ? vs[k] : vq[k], std::integral_constant<int, 0xb1>{});     // quad_perm [1,0,3,2]: lane ^ 1
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    float s = gs[pp][hf], q = gq[pp][hf];
-                    s = st_ror_add<1>(s); q = st_ror_add<1>(q);
-                    s = st_ror_add<2>(s); q = st_ror_add<2>(q);
-                    s = st_ror_add<4>(s); q = st_ror_add<4>(q);
-                    s = st_ror_add<8>(s); q = st_ror_add<8>(q);
-                    s = st_swap16_add(s); q = st_swap16_add(q);
-                    if (r == 0) { red[par][wave][4 * pp + 2 * h + hf][0] = s; red[par][wave][4 * pp + 2 * h + hf][1] = q; }
-                }
+            for (int k = 0; k < 2; ++k) t2[k] = xch(b1 ? u[2 + k] : u[k], b1 ? u[k] : u[2 + k], std::integral_constant<int, 0x4e>{});   // quad_perm [2,3,0,1]: lane ^ 2
+            t2[0] = st_ror_add<4>(t2[0]); t2[1] = st_ror_add<4>(t2[1]);
+            t2[0] = st_ror_add<8>(t2[0]); t2[1] = st_ror_add<8>(t2[1]);
+            t2[0] = st_swap16_add(t2[0]); t2[1] = st_swap16_add(t2[1]);
+            if ((lane & 28) == 0) {
+                const int g0 = 4 * (b1 ? 1 : 0) + 2 * h;      // hf = 0; hf = 1 is the next group
+                red[par][wave][g0][b0 ? 1 : 0] = t2[0];
+                red[par][wave][g0 + 1][b0 ? 1 : 0] = t2[1];
+            }
             __syncthreads();                           // (also: every wave is done with tile[par] long before it is staged again, two tiles on)
             if (tid < 8) {
                 float s = 0.f, q = 0.f;
