@@ -495,24 +495,56 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
             // GroupNorm partials: group size G = 16 or 32 here (C >= 128), slot (j, p) = 16 couts => 1 or 2 slots per group
             // all 2*NG chains advance one step at a time, side by side: every DPP reads a value written >= 3 instructions
             // earlier (no s_nop padding); then one 8-B LDS write per group
-            float rv16[NTL * 4];
+            if constexpr (NTL == 4) {
+                // 16 values (8 slots x (sum, squares)) over the 64 lanes, TRANSPOSING for the first two steps (conv_pc.hip): a lane keeps
+                // half of its values and hands the other half to its partner (lane ^ 1: the kind; lane ^ 2: slots 0..3 / 4..7), so
+                // 16 -> 8 -> 4 values per lane; those take the plain steps over lane bits 2..5.  28 cross-lane instructions
+                // instead of 96.  Lane l ends with kind b0 of slots 4 b1 .. 4 b1 + 3.
+                const bool b0 = lane & 1, b1 = lane & 2;
+                auto xch = [&](float keep, float give, auto ctrl_tag) __attribute__((always_inline)) -> float {
+                    const int gg = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), decltype(ctrl_tag)::value, 0xf, 0xf, false);
+                    return keep + __builtin_bit_cast(float, gg);
+                };
+                float u[8], t4[4];
 #pragma unroll
-            for (int g = 0; g < NTL * 2; ++g) { rv16[2 * g] = ssum[g >> 1][g & 1]; rv16[2 * g + 1] = qsum[g >> 1][g & 1]; }
+                for (int g = 0; g < 8; ++g) {
+                    const float sv = ssum[g >> 1][g & 1], qv = qsum[g >> 1][g & 1];
+                    u[g] = xch(b0 ? qv : sv, b0 ? sv : qv, std::integral_constant<int, 0xb1>{});          // quad_perm [1,0,3,2]: lane ^ 1
+                }
 #pragma unroll
-            for (int i = 0; i < NTL * 4; ++i) rv16[i] = w4_ror_add<1>(rv16[i]);
+                for (int k = 0; k < 4; ++k) t4[k] = xch(b1 ? u[4 + k] : u[k], b1 ? u[k] : u[4 + k], std::integral_constant<int, 0x4e>{});   // quad_perm [2,3,0,1]: lane ^ 2
 #pragma unroll
-            for (int i = 0; i < NTL * 4; ++i) rv16[i] = w4_ror_add<2>(rv16[i]);
+                for (int k = 0; k < 4; ++k) t4[k] = w4_ror_add<4>(t4[k]);
 #pragma unroll
-            for (int i = 0; i < NTL * 4; ++i) rv16[i] = w4_ror_add<4>(rv16[i]);
+                for (int k = 0; k < 4; ++k) t4[k] = w4_ror_add<8>(t4[k]);
 #pragma unroll
-            for (int i = 0; i < NTL * 4; ++i) rv16[i] = w4_ror_add<8>(rv16[i]);
+                for (int k = 0; k < 4; ++k) t4[k] = w4_swap16_add(t4[k]);
 #pragma unroll
-            for (int i = 0; i < NTL * 4; ++i) rv16[i] = w4_swap16_add(rv16[i]);
+                for (int k = 0; k < 4; ++k) t4[k] = w4_swap32_add(t4[k]);
+                if ((lane & 60) == 0) {
 #pragma unroll
-            for (int i = 0; i < NTL * 4; ++i) rv16[i] = w4_swap32_add(rv16[i]);
-            if (lane == 0) {
-#pragma unroll
-                for (int g = 0; g < NTL * 2; ++g) *reinterpret_cast<float2*>(red + (wave * 8 + g) * 2) = make_float2(rv16[2 * g], rv16[2 * g + 1]);
+                    for (int k = 0; k < 4; ++k) red[(wave * 8 + (b1 ? 4 : 0) + k) * 2 + (b0 ? 1 : 0)] = t4[k];
+                }
+            } else {
+                float rv16[NTL * 4];
+    #pragma unroll
+                for (int g = 0; g < NTL * 2; ++g) { rv16[2 * g] = ssum[g >> 1][g & 1]; rv16[2 * g + 1] = qsum[g >> 1][g & 1]; }
+    #pragma unroll
+                for (int i = 0; i < NTL * 4; ++i) rv16[i] = w4_ror_add<1>(rv16[i]);
+    #pragma unroll
+                for (int i = 0; i < NTL * 4; ++i) rv16[i] = w4_ror_add<2>(rv16[i]);
+    #pragma unroll
+                for (int i = 0; i < NTL * 4; ++i) rv16[i] = w4_ror_add<4>(rv16[i]);
+    #pragma unroll
+                for (int i = 0; i < NTL * 4; ++i) rv16[i] = w4_ror_add<8>(rv16[i]);
+    #pragma unroll
+                for (int i = 0; i < NTL * 4; ++i) rv16[i] = w4_swap16_add(rv16[i]);
+    #pragma unroll
+                for (int i = 0; i < NTL * 4; ++i) rv16[i] = w4_swap32_add(rv16[i]);
+                if (lane == 0) {
+    #pragma unroll
+                    for (int g = 0; g < NTL * 2; ++g) *reinterpret_cast<float2*>(red + (wave * 8 + g) * 2) = make_float2(rv16[2 * g], rv16[2 * g + 1]);
+                }
             }
             __syncthreads();
             const int G = a.group_size, spg = G >> 4, ngl = NT / G;     // slots per group (1 or 2), groups in the item
