@@ -52,6 +52,7 @@ def parse_args(argv=None):
     ap.add_argument("--precision", choices=["bf16", "fp8"], default="bf16", help="fp8: OCP e4m3 operands for the C >= 128 ResBlock convs (cfg 4)")
     ap.add_argument("--strips", type=int, default=8, help="tiled: row strips per image on ONE GPU (virtual ranks); with N > 1 ranks each rank owns one strip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the host-buffer (PCIe-inclusive) sub-record measured after the timed region")
     ap.add_argument("--no-profile", action="store_true", help="skip the in-engine HIP-event kernel timing")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel family (more events, ~5 %% slower)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # tests only: gloo + a sleep instead of the GPU step
@@ -91,26 +92,114 @@ def launch_ranks(n, argv, timeout=None):
 
 
 def cpu_baseline(size, budget_s=25.0):
-    """Oracle (CPU restatement, kind='port') on a bounded sample: three size x size images (about 15 s at 1024^2)."""
+    """Oracle (CPU restatement, kind='port') on a bounded sample (about 30 s in all): the bench workload's size with the box's
+    CPU share, then SURVEY.md 8(d)'s other rows -- 512x512 (cfg 1) and 256x256 (cfg 0, the reference's own CPU-runnable case)
+    with all threads and with ONE thread."""
     import numpy as np
     import torch
     from image_restoration_platform_amd import synth, weights
     from oracle import classifier as oc
     from oracle import restorenet as onet
-    cores = min(os.cpu_count() or 1, 16)   # a 1-GPU box's CPU share; more threads only oversubscribe
-    torch.set_num_threads(cores)
-    n = 3 if size <= 1024 else 1
-    img = synth.batch(n, size, size)
+    nproc = os.cpu_count() or 1
+    cores = min(nproc, 16)   # a 1-GPU box's CPU share; more threads only oversubscribe
     w = weights.generate(0)
+
+    def run(sz, n, threads):
+        torch.set_num_threads(threads)
+        img = synth.batch(n, sz, sz)
+        t0 = time.perf_counter()
+        sc = np.stack([oc.classify(img[i], True)[0] for i in range(n)])
+        t1 = time.perf_counter()
+        for i in range(n):          # one image at a time, as the reference's worker would (restorator.js:198-211)
+            onet.restore(img[i:i + 1], sc[i:i + 1], w)
+        t2 = time.perf_counter()
+        return n / (t2 - t0), 1e3 * (t1 - t0) / n, (t2 - t1) / n
+
+    n = 3 if size <= 1024 else 1
+    v, cls_ms, net_s = run(size, n, cores)
+    rows = {"%dx%d, %d threads" % (size, size, cores): round(v, 4)}
+    for sz, nn, th in ((512, 2, cores), (256, 2, cores), (512, 1, 1), (256, 1, 1)):
+        if sz == size and th == cores:
+            continue
+        rows["%dx%d, %d thread%s" % (sz, sz, th, "" if th == 1 else "s")] = round(run(sz, nn, th)[0], 4)
+    torch.set_num_threads(cores)
+    return {"value": v, "unit": "images/sec", "cores": cores, "nproc": nproc, "kind": "port",
+            "sample": f"{n} images {size}x{size}: C classifier oracle (1 thread) {cls_ms:.0f} ms/image + "
+                      f"PyTorch-CPU fp32 RestoreNet oracle ({cores} threads) {net_s:.1f} s/image",
+            "images_per_sec_by_config": rows}
+
+
+def host_path(eng, size, batch, jobs=64):
+    """PCIe- and copy-inclusive rate of the deployed path, measured OUTSIDE the timed region (never the bench `value`):
+    `jobs` single-image jobs through ire_submit / ire_poll (the batcher both service seams use) from one thread with 8 jobs in
+    flight (the reference keeps 3 per restoreBatch, 5 per worker: restorator.js:13-14, design.md:851), and ire_restore on host
+    batches.  The Node seams' rate is measured by tools/host_path_rate.py (needs a second engine in a node process)."""
+    import collections
+    from image_restoration_platform_amd import synth
+    x = synth.batch(batch, size, size)
+    for _ in range(2):
+        eng.restore(x)
     t0 = time.perf_counter()
-    s = np.stack([oc.classify(img[i], True)[0] for i in range(n)])
-    t1 = time.perf_counter()
-    for i in range(n):          # one image at a time, as the reference's worker would (restorator.js:198-211)
-        onet.restore(img[i:i + 1], s[i:i + 1], w)
-    t2 = time.perf_counter()
-    return {"value": n / (t2 - t0), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{n} images {size}x{size}: C classifier oracle (1 thread) {1e3 * (t1 - t0) / n:.0f} ms/image + "
-                      f"PyTorch-CPU fp32 RestoreNet oracle ({cores} threads) {(t2 - t1) / n:.1f} s/image"}
+    for _ in range(4):
+        eng.restore(x)
+    host_batch = 4 * batch / (time.perf_counter() - t0)
+    for j in [eng.submit(x[i % batch]) for i in range(2 * batch)]:
+        eng.poll(j)
+    out = {}
+    for inflight in (8, 16):
+        b0 = eng.stats()["batches"]
+        t0 = time.perf_counter()
+        q = collections.deque()
+        for i in range(jobs):
+            if len(q) == inflight:
+                eng.poll(q.popleft())
+            q.append(eng.submit(x[i % batch]))
+        while q:
+            eng.poll(q.popleft())
+        dt = time.perf_counter() - t0
+        out["submit_poll_%d_in_flight" % inflight] = {"images_per_sec": jobs / dt, "engine_batches": eng.stats()["batches"] - b0, "jobs": jobs}
+    out["ire_restore_host_batches"] = {"images_per_sec": host_batch, "batch": batch}
+    return out
+
+
+def per_level_roofline(groups, steps, counters=None):
+    """roofline.per_group / per_level: each layer group of the step against BOTH rooflines ("reporting the
+    fraction per level").  For a group: t_mfma = executed flops / MFMA peak, t_hbm = algorithmic bytes / HBM peak, the larger
+    one is the group's roofline time and names what binds it; frac_of_bound = that time / the measured time.  `counters`
+    (optional): per-group HBM bytes per launch from the committed rocprofv3 --pmc passes."""
+    rows, lv = [], {}
+    tot_roof = tot_ms = 0.0
+    for g in groups:
+        if g["launches"] == 0 or g["ms"] <= 0:
+            continue
+        t = g["ms"] * 1e-3
+        t_mfma = g["flops_executed"] / (MFMA_BF16_PEAK_TFLOPS * 1e12)
+        t_hbm = g["bytes"] / (HBM_PEAK_GBS * 1e9)
+        bound = "mfma" if t_mfma >= t_hbm else "hbm"
+        cb = (counters or {}).get(g["group"])
+        row = {"group": g["group"], "kernel": g["kernel"], "cin": g["cin"], "cout": g["cout"], "launches_per_step": g["launches"] / steps,
+               "us_per_launch": 1e3 * g["ms"] / g["launches"], "ms_per_step": g["ms"] / steps,
+               "gflop_algorithmic_per_launch": g["flops"] / g["launches"] / 1e9, "gflop_executed_per_launch": g["flops_executed"] / g["launches"] / 1e9,
+               "mb_algorithmic_per_launch": g["bytes"] / g["launches"] / 1e6,
+               "mfma_frac_algorithmic": g["flops"] / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, "mfma_frac_executed": t_mfma / t,
+               "hbm_frac_algorithmic": t_hbm / t, "bound": bound, "frac_of_bound": max(t_mfma, t_hbm) / t}
+        if cb:
+            row["mb_counter_per_launch"] = cb["hbm_bytes_per_launch"] / 1e6
+            row["hbm_frac_counter"] = cb["hbm_bytes_per_launch"] * g["launches"] / t / 1e9 / HBM_PEAK_GBS
+        rows.append(row)
+        key = g["group"].split(".")[0] if g["group"].startswith("L") else "".join(c for c in g["group"] if not c.isdigit())
+        a = lv.setdefault(key, {"ms": 0.0, "t_mfma": 0.0, "t_hbm": 0.0, "flops": 0.0, "t_roof": 0.0})
+        a["ms"] += g["ms"]; a["t_mfma"] += t_mfma; a["t_hbm"] += t_hbm; a["flops"] += g["flops"]; a["t_roof"] += max(t_mfma, t_hbm)
+        if g["group"].startswith(("L", "up", "down")):
+            tot_roof += max(t_mfma, t_hbm); tot_ms += g["ms"]
+    per_level = {k: {"ms_per_step": v["ms"] / steps, "mfma_frac_algorithmic": v["flops"] / (v["ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                     "mfma_frac_executed": v["t_mfma"] / (v["ms"] * 1e-3), "hbm_frac_algorithmic": v["t_hbm"] / (v["ms"] * 1e-3),
+                     "bound": "mfma" if v["t_mfma"] >= v["t_hbm"] else "hbm", "frac_of_bound": v["t_roof"] / (v["ms"] * 1e-3)}
+                 for k, v in sorted(lv.items())}
+    return {"per_group": rows, "per_level": per_level,
+            "frac_of_per_layer_roofline": (tot_roof / (tot_ms * 1e-3)) if tot_ms > 0 else None,
+            "per_layer_roofline_note": "sum over the conv3x3 layer groups of max(executed flops / 2.5 PFLOP/s, algorithmic bytes / 8 TB/s) divided by their measured time: "
+                                       "1.0 = every layer on whichever table roofline binds it"}
 
 
 class Ctx:
@@ -209,6 +298,7 @@ def run_restore(ctx, eng):
     if not a.no_profile:
         eng.profile_enable(0)
         prof = {f: eng.profile_query(f) for f in ("conv3x3", "conv1x1", "stem", "head", "classifier", "gn_finalize", "all")}
+        report = eng.profile_report()
     if ctx.rank != 0:
         return
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
@@ -222,24 +312,34 @@ def run_restore(ctx, eng):
         c3 = prof["conv3x3"]
         # HBM bytes per launch from PMC counters cannot be collected from inside this process; they come from the committed
         # rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled per MI355X_MICROARCH.md), valid for 1024x1024 bs=8 only.
-        traffic, traffic_src = None, None
-        for name in ("r02_traffic.json", "r01_traffic.json"):
+        traffic, traffic_src, tr = None, None, None
+        for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             tj = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tj) and S == 1024 and B == 8:
                 with open(tj) as f:
                     tr = json.load(f)
-                traffic, traffic_src = tr["hbm_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % name
+                traffic, traffic_src = tr["hbm_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; a recorded constant, not a measurement of this run)" % name
                 break
         ach = c3["flops"] / (c3["ms"] * 1e-3) / 1e12 if c3["ms"] > 0 else 0.0
+        groups = report          # mode 2 (default): the conv3x3 family's groups only; --profile-all adds stem / head / 1x1
+        g3 = [g for g in groups if g["group"].startswith(("L", "up", "down"))]          # the conv3x3 family's layer groups
+        exec3 = sum(g["flops_executed"] for g in g3)
+        ach_x = exec3 / (c3["ms"] * 1e-3) / 1e12 if c3["ms"] > 0 and g3 else None
         res["roofline"] = {
-            "kernel": "conv3x3 family: every 3x3 convolution kernel of the step (ResBlock convs incl. their folded GroupNorm finalize, stride-2 down, up composed with the 1x1 fuse: its flops are counted)", "bound": "mfma",
+            "kernel": "conv3x3 family: every 3x3 convolution kernel of the step (ResBlock convs incl. their folded GroupNorm finalize, stride-2 down, up composed with the 1x1 fuse)", "bound": "mfma",
             "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+            "frac_note": "frac = ALGORITHMIC flops (2*9*Cin*Cout per output pixel; for `up` also the 1x1 fuse it is composed with) / time / peak; "
+                         "frac_executed counts what the MFMA pipe really issues (the sub-pixel `up` form runs 4 of 9 taps + the skip half of the fuse): use it as MFMA-pipe utilisation",
+            "achieved_executed": ach_x, "frac_executed": (ach_x / MFMA_BF16_PEAK_TFLOPS) if ach_x is not None else None,
             "traffic": traffic, "traffic_source": traffic_src, "launches": c3["launches"], "avg_launch_us": 1e3 * c3["ms"] / max(1, c3["launches"]),
             "algorithmic_gflop_per_launch": c3["flops"] / max(1, c3["launches"]) / 1e9,
             "hbm_algorithmic_GBs": c3["bytes"] / (c3["ms"] * 1e-3) / 1e9 if c3["ms"] > 0 else 0.0,
             "family_ms_per_step": {k: v["ms"] / a.steps for k, v in prof.items()},
         }
+        res["roofline"].update(per_level_roofline(groups, a.steps, (tr or {}).get("per_group")))
         res["whole_net_mfma_frac"] = (f3 + f1) * B * a.steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS
+    if ctx.world == 1 and not a.no_host_path:
+        res["host_path"] = host_path(eng, S, B)
     if ctx.world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(S)
     print(json.dumps(res))

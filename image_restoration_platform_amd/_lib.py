@@ -68,6 +68,7 @@ SYMBOLS = {
     "ire_profile_query": (_i, [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
                                ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "ire_profile_reset": (_i, [_vp]),
+    "ire_profile_report": (_i, [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
 }
 
 _lib = None

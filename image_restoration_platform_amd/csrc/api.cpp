@@ -31,7 +31,12 @@ struct Job {
 }  // namespace ire
 
 struct ire_job { std::shared_ptr<ire::Job> j; };
-struct ire_strips { std::unique_ptr<ire::StripSession> s; };
+// A strip session belongs to an engine: ire_shutdown and ire_load_weights must not pull the engine (or its layer program)
+// from under an open session.  The engine keeps a registry of its open sessions; shutdown closes their inner objects (the
+// caller's handle stays valid as an empty shell: every later call on it returns IRE_ERR_INVALID_INPUT "invalid strip
+// session handle" and ire_strips_close only frees the shell), load_weights refuses while sessions are open.
+struct ire_strips { std::unique_ptr<ire::StripSession> s; ire_engine* owner = nullptr; };
+static std::mutex g_strips_mu;       // guards every ire_engine::sessions list and every ire_strips::s / owner
 
 struct ire_engine {
     std::unique_ptr<ire::Engine> eng;
@@ -42,6 +47,7 @@ struct ire_engine {
     std::thread worker;
     bool stop = false;
     int device = 0;
+    std::vector<ire_strips*> sessions;     // open strip sessions (g_strips_mu)
     ~ire_engine() {
         {
             std::lock_guard<std::mutex> lk(qmu);
@@ -49,6 +55,12 @@ struct ire_engine {
         }
         qcv.notify_all();
         if (worker.joinable()) worker.join();
+        std::lock_guard<std::mutex> lk(g_strips_mu);
+        for (ire_strips* s : sessions) {       // invalidate: the StripSession dies with its engine, the caller's shell survives
+            if (eng) { std::lock_guard<std::mutex> lk2(eng->mutex()); s->s.reset(); } else s->s.reset();
+            s->owner = nullptr;
+        }
+        sessions.clear();
     }
 };
 
@@ -267,6 +279,7 @@ int ire_init(const ire_config* cfg, ire_engine** out) {
     return guarded([&] {
         if (!cfg || !out) fail(IRE_ERR_INVALID_INPUT, "invalid arguments to ire_init");
         if (cfg->struct_size < sizeof(ire_config)) fail(IRE_ERR_INVALID_INPUT, "invalid ire_config.struct_size");
+        if (cfg->flags != 0) fail(IRE_ERR_INVALID_INPUT, "invalid ire_config.flags (reserved, must be 0)");
         *out = nullptr;
         std::unique_ptr<ire_engine> E(new ire_engine());
         E->eng.reset(new Engine(*cfg));
@@ -281,6 +294,10 @@ int ire_load_weights(ire_engine* e, const void* blob, size_t bytes) {
     return guarded([&] {
         Engine& E = eng(e);
         if (!blob) fail(IRE_ERR_INVALID_INPUT, "invalid weight blob");
+        {
+            std::lock_guard<std::mutex> lk(g_strips_mu);     // a session walks the layer program op by op: it must not change under it
+            if (!e->sessions.empty()) fail(IRE_ERR_INVALID_INPUT, "invalid call: ire_load_weights while strip sessions are open (close them first)");
+        }
         std::lock_guard<std::mutex> lk(E.mutex());
         E.load_weights(blob, bytes);
     });
@@ -386,16 +403,29 @@ int ire_strips_open(ire_engine* e, int h, int w, int nstrips_total, int first_st
         Engine& E = eng(e);
         if (!out) fail(IRE_ERR_INVALID_INPUT, "invalid arguments to ire_strips_open");
         *out = nullptr;
-        std::lock_guard<std::mutex> lk(E.mutex());
         std::unique_ptr<ire_strips> S(new ire_strips());
-        S->s.reset(new StripSession(E, h, w, nstrips_total, first_strip, nlocal, (float*)d_stats_all));
+        {
+            std::lock_guard<std::mutex> lk(E.mutex());
+            S->s.reset(new StripSession(E, h, w, nstrips_total, first_strip, nlocal, (float*)d_stats_all));
+        }
+        std::lock_guard<std::mutex> lk(g_strips_mu);
+        S->owner = e;
+        e->sessions.push_back(S.get());
         *out = S.release();
     });
 }
 
 void ire_strips_close(ire_strips* s) {
     if (!s) return;
-    if (s->s) { std::lock_guard<std::mutex> lk(s->s->engine().mutex()); s->s.reset(); }
+    {
+        std::lock_guard<std::mutex> lk(g_strips_mu);
+        if (s->owner) {       // the engine is alive: unregister, then free the session under the engine's lock
+            auto& v = s->owner->sessions;
+            for (size_t i = 0; i < v.size(); ++i) if (v[i] == s) { v.erase(v.begin() + i); break; }
+            if (s->s) { std::lock_guard<std::mutex> lk2(s->s->engine().mutex()); s->s.reset(); }
+            s->owner = nullptr;
+        }
+    }
     delete s;
 }
 
@@ -540,6 +570,22 @@ int ire_profile_query(ire_engine* e, const char* family, double* ms_out, int64_t
         const int fam = family_id(family);
         std::lock_guard<std::mutex> lk(E.mutex());
         E.profile_query(fam, ms_out, launches_out, flops_out, bytes_out);
+    });
+}
+
+int ire_profile_report(ire_engine* e, char* buf, size_t cap, size_t* needed_out) {
+    return guarded([&] {
+        Engine& E = eng(e);
+        std::string r;
+        {
+            std::lock_guard<std::mutex> lk(E.mutex());
+            r = E.profile_report();
+        }
+        if (needed_out) *needed_out = r.size() + 1;
+        if (buf && cap) {
+            if (cap < r.size() + 1) fail(IRE_ERR_INVALID_INPUT, "invalid buffer size for ire_profile_report (query *needed_out first)");
+            std::memcpy(buf, r.c_str(), r.size() + 1);
+        }
     });
 }
 

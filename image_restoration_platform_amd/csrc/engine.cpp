@@ -81,6 +81,7 @@ Engine::Engine(const ire_config& cfg) {
     if (max_batch_ > 64) fail(IRE_ERR_INVALID_INPUT, "invalid max_batch (1..64)");
     num_lanes_ = cfg.num_streams > 0 ? cfg.num_streams : 1;
     if (num_lanes_ > 16) num_lanes_ = 16;
+    if (cfg.flags != 0) fail(IRE_ERR_INVALID_INPUT, "invalid ire_config.flags (reserved, must be 0)");
     flags_ = cfg.flags;
     if (const char* v = std::getenv("IRE_CONV_V1")) rb_tile_h_ = (v[0] == '1') ? 8 : kRbTileH;
     if (const char* v = std::getenv("IRE_ACT_SPLIT_MINC")) act_split_min_c_ = std::atoi(v);
@@ -658,7 +659,7 @@ void Engine::prof_begin(int fam, hipStream_t s, double flops, double bytes) {
     prof_open_ = prof_on_ == 1 || (prof_on_ == 2 && fam == FAM_CONV3);   // mode 2: dominant family only (fewer events)
     if (!prof_open_) { prof_chain_ = false; return; }
     ProfRec r;
-    r.fam = fam; r.flops = flops; r.bytes = bytes;
+    r.fam = fam; r.flops = flops; r.bytes = bytes; r.flops_exec = flops;
     auto get = [&]() {
         hipEvent_t ev;
         if (!ev_pool_.empty()) { ev = ev_pool_.back(); ev_pool_.pop_back(); }
@@ -671,6 +672,13 @@ void Engine::prof_begin(int fam, hipStream_t s, double flops, double bytes) {
     else { r.e0 = get(); IRE_HIP(hipEventRecord(r.e0, s)); }
     r.e1 = get();
     prof_.push_back(r);
+}
+void Engine::prof_tag(const std::string& key, const char* kernel, int level, int cin, int cout, double flops_exec) {
+    if (!prof_open_) return;
+    int gi = -1;
+    for (size_t i = 0; i < prof_groups_.size(); ++i) if (prof_groups_[i].key == key) { gi = (int)i; break; }
+    if (gi < 0) { ProfGroup g; g.key = key; g.kernel = kernel; g.level = level; g.cin = cin; g.cout = cout; prof_groups_.push_back(g); gi = (int)prof_groups_.size() - 1; }
+    prof_.back().group = gi; prof_.back().flops_exec = flops_exec;
 }
 void Engine::prof_end(hipStream_t s) {
     if (!prof_open_) return;
@@ -685,6 +693,8 @@ void Engine::prof_collect() {
         float ms = 0.f;
         IRE_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
         prof_ms_[r.fam] += ms; prof_flops_[r.fam] += r.flops; prof_bytes_[r.fam] += r.bytes; prof_n_[r.fam] += 1;
+        prof_flops_exec_[r.fam] += r.flops_exec;
+        if (r.group >= 0) { ProfGroup& g = prof_groups_[r.group]; g.ms += ms; g.flops += r.flops; g.flops_exec += r.flops_exec; g.bytes += r.bytes; g.n += 1; }
         if (r.own_e0) ev_pool_.push_back(r.e0);
         ev_pool_.push_back(r.e1);
     }
@@ -693,7 +703,21 @@ void Engine::prof_collect() {
 void Engine::profile_enable(int mode) { prof_collect(); prof_on_ = mode; }
 void Engine::profile_reset() {
     prof_collect();
-    for (int i = 0; i < FAM_COUNT; ++i) { prof_ms_[i] = prof_flops_[i] = prof_bytes_[i] = 0; prof_n_[i] = 0; }
+    for (int i = 0; i < FAM_COUNT; ++i) { prof_ms_[i] = prof_flops_[i] = prof_bytes_[i] = prof_flops_exec_[i] = 0; prof_n_[i] = 0; }
+    prof_groups_.clear();
+}
+std::string Engine::profile_report() {
+    prof_collect();
+    std::string out = "[";
+    char buf[512];
+    for (size_t i = 0; i < prof_groups_.size(); ++i) {
+        const ProfGroup& g = prof_groups_[i];
+        std::snprintf(buf, sizeof buf, "%s{\"group\": \"%s\", \"kernel\": \"%s\", \"level\": %d, \"cin\": %d, \"cout\": %d, \"launches\": %lld, "
+                      "\"ms\": %.6f, \"flops\": %.6e, \"flops_executed\": %.6e, \"bytes\": %.6e}",
+                      i ? ", " : "", g.key.c_str(), g.kernel.c_str(), g.level, g.cin, g.cout, (long long)g.n, g.ms, g.flops, g.flops_exec, g.bytes);
+        out += buf;
+    }
+    return out + "]";
 }
 void Engine::profile_query(int fam, double* ms, int64_t* launches, double* flops, double* bytes) {
     prof_collect();
@@ -889,40 +913,60 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
         } else flush_gn(R, g);
     }
     prof_begin(fam, R.stream, flops, bytes);
+    const char* kname = "conv_mfma";       // which kernel takes this launch (the branches below)
     const bool pc_hi = rb && rb_tile_h_ == kRbTileH && (pc_split_ & 4) && cw.cout >= 128 && cw.cin == cw.cout && a.ab != nullptr && cw.d_wp != nullptr &&
                        cw.d_w8 == nullptr && conv_pc_fits(cw.cout, a.tiles_x * a.tiles_y, g.nimg);       // (fp8 engines keep conv_f8 / conv_w4)
     if (pc_hi) {
         a.w = cw.d_wp;
-        conv_pc_launch(cw.kind == CONV_RB2, false, a, R.stream);
+        conv_pc_launch(cw.kind == CONV_RB2, false, a, R.stream); kname = "conv_pc";
     } else if (w4 && fp8_mx_ && cw.d_w8x != nullptr && a.ab != nullptr) {   // IRE_PRECISION_FP8: the 2x-rate block-scaled fp8 MFMA
         a.fp8 = 1; a.w = reinterpret_cast<const unsigned short*>(cw.d_w8x); a.bias = cw.d_bias8; a.oscale = cw.d_oscale;
         a.nkc = cw.cin / 32; a.nblocks = cw.cout / 128;
-        conv_f8_launch(cw.kind == CONV_RB2, a, R.stream);
+        conv_f8_launch(cw.kind == CONV_RB2, a, R.stream); kname = "conv_f8";
     } else if (w4) {
         a.w = cw.d_w4; a.nkc = cw.cin / 16; a.nblocks = cw.cout / 128;
         if (cw.d_w8 != nullptr && a.ab != nullptr) {      // IRE_PRECISION_FP8: e4m3 operands for the C >= 128 ResBlock convs
             a.fp8 = 1; a.w = reinterpret_cast<const unsigned short*>(cw.d_w8); a.bias = cw.d_bias8; a.oscale = cw.d_oscale;
         }
-        conv_w4_launch(cw.kind == CONV_RB2, a, R.stream);
-    } else if (head_rb) { a.w = cw.d_wp; if (pc_split_ & 1) conv_pc_launch(false, true, a, R.stream); else conv_head_launch(a, R.stream); }
-    else if (down_rb) { a.w = cw.d_wd; a.nkc = cw.cin / 32; a.nblocks = cw.cout / 64; conv_down_launch(a, R.stream); }
-    else if (stem_rb) { a.w = cw.d_wstem; conv_stem_launch(a, R.stream); }
+        conv_w4_launch(cw.kind == CONV_RB2, a, R.stream); kname = "conv_w4";
+    } else if (head_rb) { a.w = cw.d_wp; if (pc_split_ & 1) { conv_pc_launch(false, true, a, R.stream); kname = "conv_pc"; } else { conv_head_launch(a, R.stream); kname = "conv_rb"; } }
+    else if (down_rb) { a.w = cw.d_wd; a.nkc = cw.cin / 32; a.nblocks = cw.cout / 64; conv_down_launch(a, R.stream); kname = "conv_down"; }
+    else if (stem_rb) { a.w = cw.d_wstem; conv_stem_launch(a, R.stream); kname = "conv_stem"; }
     else if (up_fused) {
         a.w = cw.d_wuf; a.w1 = cw.d_wsk; a.bias = cw.d_bias_uf; a.nkc = cw.cin / 32; a.nblocks = cw.cout / 32;
         a.in1 = in_ptr(op.in1) + (size_t)g.halo * Wout * cw.cout;      // the skip tensor is read at output pixels only: first real row
         a.cin1 = cw.cout;
-        conv_up_subpixel_launch(a, R.stream);
+        conv_up_subpixel_launch(a, R.stream); kname = "conv_up";
     }
-    else if (up_sub) { a.in1 = nullptr; a.w = cw.d_wu; a.nkc = cw.cin / 32; a.nblocks = cw.cout / 32; conv_up_subpixel_launch(a, R.stream); }
-    else if (up_rb) { if (cw.d_wp) a.w = cw.d_wp; conv_up_launch(a, R.stream); }
+    else if (up_sub) { a.in1 = nullptr; a.w = cw.d_wu; a.nkc = cw.cin / 32; a.nblocks = cw.cout / 32; conv_up_subpixel_launch(a, R.stream); kname = "conv_up"; }
+    else if (up_rb) { if (cw.d_wp) a.w = cw.d_wp; conv_up_launch(a, R.stream); kname = "conv_rb"; }
     else if (rb && rb_tile_h_ == kRbTileH) {
         if (cw.d_wp) a.w = cw.d_wp;
         const bool pc = a.ab != nullptr && cw.d_wp && cw.cin == cw.cout &&
                         ((cw.cout == 32 && (pc_split_ & 1)) || (cw.cout == 64 && (pc_split_ & 2))) && conv_pc_fits(cw.cout, a.tiles_x * a.tiles_y, g.nimg);
-        if (pc) conv_pc_launch(cw.kind == CONV_RB2, false, a, R.stream);
-        else conv_rb_launch(cw.kind == CONV_RB2, /*fused_act=*/a.ab != nullptr, a, R.stream);
+        if (pc) { conv_pc_launch(cw.kind == CONV_RB2, false, a, R.stream); kname = "conv_pc"; }
+        else { conv_rb_launch(cw.kind == CONV_RB2, /*fused_act=*/a.ab != nullptr, a, R.stream); kname = "conv_rb"; }
     }
     else conv_launch(cw.kind, a, R.stream);
+    {
+        // layer group of this launch (bench.py roofline.per_level) and the flops the kernel really issues: the sub-pixel `up`
+        // form runs 4 of the 9 taps, its composed `fuse` only the skip half of the 1x1 (the up half is folded into the weights)
+        double fexec = flops;
+        if (up_fused) fexec = 2.0 * 4 * cw.cin * cw.cout * px + 2.0 * cw.cout * cw.cout * px;
+        else if (up_sub) fexec = 2.0 * 4 * cw.cin * cw.cout * px;
+        std::string key;
+        switch (cw.kind) {
+            case CONV_RB1: key = "L" + std::to_string(op.lout) + ".rb1"; break;
+            case CONV_RB2: key = "L" + std::to_string(op.lout) + ".rb2"; break;
+            case CONV_DOWN: key = "down" + std::to_string(op.lin); break;
+            case CONV_UP: key = "up" + std::to_string(op.lout); break;
+            case CONV_FUSE: key = "fuse" + std::to_string(op.lout); break;
+            case CONV_STEM: key = "stem"; break;
+            case CONV_HEAD: key = "head"; break;
+            default: key = "conv"; break;
+        }
+        prof_tag(key, kname, op.lout, cw.cin, cw.cout, fexec);
+    }
     prof_end(R.stream);
     if (op.stats_out) {
         const int sl = up_fused ? op.lin : op.lout;
@@ -1057,6 +1101,11 @@ void Engine::restore_tiled_device(const uint8_t* d_rgb, int h, int w, int nstrip
         d_scores = d_scores_;
     }
     batches_run_ += 1; images_restored_ += 1; last_batch_ = 1;
+    {
+        const double t = now_s();          // tiled jobs count in the images/sec gauge like whole-batch calls
+        recent_.emplace_back(t, 1);
+        while (!recent_.empty() && recent_.front().first < t - 10.0) recent_.pop_front();
+    }
     tiled_->run_all(d_rgb, d_scores, d_out, stream);
 }
 

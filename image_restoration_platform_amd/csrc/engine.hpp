@@ -117,6 +117,14 @@ struct ProfRec {
     bool own_e0 = true;   // false: e0 is the previous record's e1 (back-to-back profiled launches share the event)
     hipEvent_t e0, e1;
     double flops, bytes;
+    double flops_exec = 0;   // flops the kernel really issues (the sub-pixel `up` form runs 4 of 9 taps, its composed skip term C of 2C channels)
+    int group = -1;          // index into Engine::prof_groups_ (layer group "L2.rb1", "up0", ...) or -1
+};
+struct ProfGroup {           // per layer group: what bench.py's roofline.per_level reports
+    std::string key, kernel;
+    int level = 0, cin = 0, cout = 0;
+    double ms = 0, flops = 0, flops_exec = 0, bytes = 0;
+    int64_t n = 0;
 };
 
 class Engine {
@@ -158,6 +166,7 @@ public:
     void profile_enable(int mode);   // 0 off, 1 every kernel family, 2 the 3x3 conv family only
     void profile_reset();
     void profile_query(int fam, double* ms, int64_t* launches, double* flops, double* bytes);
+    std::string profile_report();    // JSON array, one object per layer group (ire_profile_report)
 
     int max_batch() const { return max_batch_; }
     // Cross-stream serialisation of the shared GPU scratch (activation workspaces, d_scores_, d_film_, fusion and
@@ -193,6 +202,7 @@ private:
     void exec_conv(Run& R, const Op& op, const Geo& g);
     static Geo geo_of_lane(const Lane& L, int nimg, int h, int w, const uint8_t* d_in, uint8_t* d_out);
     void prof_begin(int fam, hipStream_t s, double flops, double bytes);
+    void prof_tag(const std::string& key, const char* kernel, int level, int cin, int cout, double flops_exec);   // after prof_begin: the open record's layer group
     void prof_end(hipStream_t s);
     void capture(const char* name, const unsigned short* d, size_t count, hipStream_t s);
     ConvW make_conv(ConvKind kind, const std::string& wname, const std::string& bname, int cin, int cout);
@@ -289,6 +299,8 @@ private:
     std::vector<hipEvent_t> ev_pool_;
     double prof_ms_[FAM_COUNT] = {}, prof_flops_[FAM_COUNT] = {}, prof_bytes_[FAM_COUNT] = {};
     int64_t prof_n_[FAM_COUNT] = {};
+    double prof_flops_exec_[FAM_COUNT] = {};
+    std::vector<ProfGroup> prof_groups_;
     void prof_collect();
 };
 

@@ -50,6 +50,11 @@ class Engine:
         self._h = h
         self.max_batch = max_batch
 
+    def load_weights(self, blob):
+        """RestoreNet-v0 weights from memory (the bytes of a weight file): ire_load_weights."""
+        b = bytes(blob)
+        self._check(self._lib.ire_load_weights(self._h, b, len(b)))
+
     def _check(self, rc):
         if rc != 0:
             msg = self._lib.ire_last_error()
@@ -57,6 +62,11 @@ class Engine:
 
     def close(self):
         if getattr(self, "_h", None):
+            for ref in getattr(self, "_sessions", []):     # open strip sessions die with their engine (ire_shutdown would only
+                s = ref()                                  # leave them as empty shells): close them first
+                if s is not None:
+                    s.close()
+            self._sessions = []
             self._lib.ire_shutdown(self._h)
             self._h = None
 
@@ -245,7 +255,12 @@ class Engine:
         return out_u8
 
     def open_strips(self, h, w, nstrips_total, first_strip, nlocal=1):
-        return StripSession(self, h, w, nstrips_total, first_strip, nlocal)
+        import weakref
+        s = StripSession(self, h, w, nstrips_total, first_strip, nlocal)
+        if not hasattr(self, "_sessions"):
+            self._sessions = []
+        self._sessions = [r for r in self._sessions if r() is not None] + [weakref.ref(s)]
+        return s
 
     # ---- diagnostics --------------------------------------------------------------------------
     def classifier_sums(self, n):
@@ -275,6 +290,15 @@ class Engine:
         self._check(self._lib.ire_profile_query(self._h, family.encode(), ctypes.byref(ms), ctypes.byref(n),
                                                 ctypes.byref(fl), ctypes.byref(by)))
         return {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+
+    def profile_report(self):
+        """Per-layer-group rows of the profiled convolution launches since the last reset (ire_profile_report)."""
+        import json
+        need = ctypes.c_size_t(0)
+        self._check(self._lib.ire_profile_report(self._h, None, 0, ctypes.byref(need)))
+        buf = ctypes.create_string_buffer(need.value + 64)
+        self._check(self._lib.ire_profile_report(self._h, buf, len(buf), ctypes.byref(need)))
+        return json.loads(buf.value.decode())
 
 
 class StripSession:

@@ -48,5 +48,6 @@ export function bindIre(libPath) {
     ire_profile_enable: ['int', [P, 'int']],
     ire_profile_query: ['int', [P, 'string', P, P, P, P]],
     ire_profile_reset: ['int', [P]],
+    ire_profile_report: ['int', [P, P, 'size_t', P]],
   });
 }

@@ -22,10 +22,12 @@
  * engine never keeps an input pointer past return (past ire_poll completion for
  * ire_submit); one engine may be used from several threads; no exceptions cross
  * the ABI.  Every call returns an ire_status; ire_last_error() gives the
- * thread-local message, which always contains one of the substrings
- * "invalid", "timeout", "service unavailable" so that the reference's
- * RestoratorService._classifyError (restorator.js:241-265) maps it the way it
- * maps provider errors.  Images are decoded 8-bit sRGB, NHWC interleaved RGB
+ * thread-local message.  Messages of IRE_ERR_INVALID_INPUT / _TIMEOUT /
+ * _UNAVAILABLE contain "invalid" / "timeout" / "service unavailable", so the
+ * reference's RestoratorService._classifyError (restorator.js:241-265) maps
+ * them the way it maps provider errors; IRE_ERR_INTERNAL messages start with
+ * "internal:" and fall through to UNKNOWN_ERROR there, which is how the
+ * reference treats a provider error it does not recognise (restorator.js:262-264).  Images are decoded 8-bit sRGB, NHWC interleaved RGB
  * (what sharp(buf).raw() yields: SURVEY.md Appendix A.1); decode/encode lives
  * in the host adapters.  There is NO CPU fallback: without a gfx950 device
  * ire_init fails with IRE_ERR_UNAVAILABLE.
@@ -214,6 +216,12 @@ int ire_profile_enable(ire_engine* e, int mode /* 0 off, 1 all families, 2 conv3
 int ire_profile_query(ire_engine* e, const char* family, double* ms_out, int64_t* launches_out,
                       double* flops_out, double* bytes_out);
 int ire_profile_reset(ire_engine* e);
+/* Per-layer-group breakdown of the profiled convolution launches since the last reset, as a JSON array of
+ * {"group" ("L0.rb1" .. "L3.rb2", "down0".., "up0".., "stem", "head"), "kernel", "level", "cin", "cout", "launches", "ms",
+ *  "flops" (algorithmic), "flops_executed" (what the kernel issues: the sub-pixel `up` form runs 4 of 9 taps), "bytes"
+ *  (algorithmic HBM bytes)} written to buf (cap bytes, NUL-terminated).  *needed_out = bytes required; call with
+ * buf == NULL to size the buffer.  bench.py's roofline.per_level is computed from this. */
+int ire_profile_report(ire_engine* e, char* buf, size_t cap, size_t* needed_out);
 
 #ifdef __cplusplus
 }

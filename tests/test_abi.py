@@ -49,6 +49,11 @@ def test_invalid_config_is_reported_not_crashed():
     assert lib.ire_init(ctypes.byref(cfg), ctypes.byref(h)) == _lib.IRE_ERR_INVALID_INPUT
     assert b"invalid" in lib.ire_last_error()
     assert lib.ire_init(None, ctypes.byref(h)) == _lib.IRE_ERR_INVALID_INPUT
+    cfg.struct_size = ctypes.sizeof(_lib.IreConfig)
+    cfg.flags = 1         # reserved: must be 0 (checked before any device is touched)
+    assert lib.ire_init(ctypes.byref(cfg), ctypes.byref(h)) == _lib.IRE_ERR_INVALID_INPUT
+    assert b"flags" in lib.ire_last_error()
+    assert lib.ire_profile_report(None, None, 0, None) == _lib.IRE_ERR_INVALID_INPUT
     # null engine handles are rejected, not dereferenced
     assert lib.ire_classify(None, None, 1, 8, 8, 24, None, None, None) == _lib.IRE_ERR_INVALID_INPUT
     assert lib.ire_profile_reset(None) == _lib.IRE_ERR_INVALID_INPUT

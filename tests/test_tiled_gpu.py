@@ -148,3 +148,54 @@ def test_fp8_tiled_equals_fp8_untiled(engine_fp8):
     tiled = engine_fp8.restore_tiled_tensor(img, 4)
     torch.cuda.synchronize()
     assert torch.equal(tiled, whole)
+
+
+def test_fp8_2048_in_8_strips_equals_fp8_untiled(engine_fp8):
+    """BASELINE.json configs[4] as stated: 2048x2048 (the reference's upload cap, imagePreprocess.js:4), fp8 conv MFMA, 8 row
+    strips (one per GPU of the node; here 8 virtual ranks).  Bit-identical to the fp8 engine's untiled run."""
+    import torch
+    img = torch.from_numpy(synth.batch(1, 2048, 2048, start=3)[0]).cuda()
+    whole = engine_fp8.restore_tensor(img[None])[0].clone()
+    tiled = engine_fp8.restore_tiled_tensor(img, 8).clone()
+    again = engine_fp8.restore_tiled_tensor(img, 8)
+    torch.cuda.synchronize()
+    assert torch.equal(tiled, whole), int((tiled.int() - whole.int()).abs().max())
+    assert torch.equal(again, whole)
+    assert (whole.int() - img.int()).abs().float().mean().item() > 1.0
+
+
+def test_fp8_tiled_multi_strip_meets_the_stated_tolerance(engine_fp8, weights0):
+    """A multi-strip fp8 run (512x512 in 4 strips of 128 rows) against the fp32 oracle itself: max <= 6 LSB, PSNR >= 38 dB."""
+    import torch
+    from oracle import classifier as oc
+    from oracle import restorenet as onet
+    img_np = synth.batch(1, 512, 512, start=21)
+    sc = np.stack([oc.classify(img_np[0], True)[0]])
+    img = torch.from_numpy(img_np[0]).cuda()
+    out = engine_fp8.restore_tiled_tensor(img, 4, scores=torch.from_numpy(sc[0]).cuda()).cpu().numpy()
+    ref = onet.restore(img_np, sc, weights0)[0]
+    d = np.abs(out.astype(np.int32) - ref.astype(np.int32))
+    mse = float(np.mean((out.astype(np.float64) - ref.astype(np.float64)) ** 2))
+    psnr = 10 * np.log10(255.0 ** 2 / max(mse, 1e-12))
+    assert d.max() <= FP8_MAX_LSB and psnr >= FP8_MIN_PSNR, (int(d.max()), psnr)
+
+
+def test_sessions_do_not_outlive_their_engine():
+    """ire_shutdown with a strip session still open leaves the caller's handle an empty shell (every call on it reports an invalid
+    handle, closing it is safe); ire_load_weights refuses while a session is open (the layer program must not change under it)."""
+    import ctypes
+    from image_restoration_platform_amd import _lib, weights
+    from image_restoration_platform_amd.engine import Engine, EngineError
+    eng = Engine(device_index=0, max_batch=1)
+    sess = eng.open_strips(256, 64, 2, 0, 1)
+    with pytest.raises(EngineError) as e:
+        eng.load_weights(open(weights.ensure_default(0), 'rb').read())
+    assert e.value.status == _lib.IRE_ERR_INVALID_INPUT and "strip sessions" in e.value.message
+    h, s = eng._h, sess._s
+    eng._sessions = []                 # bypass Engine.close()'s own clean-up: exercise the ABI's invalidation
+    eng._lib.ire_shutdown(h)
+    eng._h = None
+    assert eng._lib.ire_strips_num_ops(s) == 0
+    assert eng._lib.ire_strips_run_op(s, 0, None, None) == _lib.IRE_ERR_INVALID_INPUT
+    assert b"invalid strip session" in eng._lib.ire_last_error()
+    sess.close()                       # frees the shell only

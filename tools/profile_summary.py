@@ -47,6 +47,40 @@ def _sum(path, counter):
     return per
 
 
+def group_of(name, k):
+    """Layer group (bench.py roofline.per_group key) of the k-th dispatch (0-based, within one step) of kernel `name`.
+    The step's op order is fixed (engine.cpp::build_program): enc0..3, mid, dec2..0; the C >= 128 kernels serve level 2
+    (enc2, dec2) and level 3 (enc3, mid) with ONE instantiation each, so the position in the step tells the level."""
+    n = name.rstrip()
+    if "conv_w4_kernel" in n or "conv_f8_kernel" in n:
+        resid = "<128, 8, true" in n or n.startswith("void ire::(anonymous namespace)::conv_f8_kernel<true") or "conv_f8_kernel<true" in n
+        lvl = [2, 2, 3, 3, 3, 3, 2, 2][k % 8]
+        return "L%d.rb%d" % (lvl, 2 if resid else 1)
+    if "conv_pc_kernel<" in n or "conv_rb_kernel<" in n:
+        args = n[n.find("<") + 1:n.find(">")].replace(" ", "").split(",")
+        if args[-1] == "true":
+            return "head"
+        lvl = {"32": 0, "64": 1}.get(args[0])
+        if lvl is None:
+            return None
+        return "L%d.rb%d" % (lvl, 2 if args[1] == "true" else 1)
+    if "conv_down_kernel" in n:
+        return "down%d" % (k % 3)
+    if "conv_up_kernel<" in n:
+        return {"2": "up0", "4": "up1", "8": "up2"}.get(n[n.find("<") + 1:n.find(">")])
+    if "conv_stem_kernel" in n:
+        return "stem"
+    return None
+
+
+def _per_dispatch(path, counter):
+    per = defaultdict(list)       # kernel -> [(dispatch id, value)]
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            per[r["Kernel_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+    return {k: [v for _, v in sorted(rows)] for k, rows in per.items()}
+
+
 def traffic(fetch_csv, write_csv, dst, steps):
     steps = int(steps)
     fe, wr = _sum(fetch_csv, "FETCH_SIZE"), _sum(write_csv, "WRITE_SIZE")
@@ -68,6 +102,21 @@ def traffic(fetch_csv, write_csv, dst, steps):
         tot_w += w
         launches += n
         out["per_kernel"][k[k.find("conv_"):][:100]] = {"launches": n // steps, "fetch_MiB_corrected": round(f / n / 2 ** 20, 1), "write_MiB": round(w / n / 2 ** 20, 1)}
+    # per layer group (the same counters, dispatch by dispatch in launch order)
+    fd, wd = _per_dispatch(fetch_csv, "FETCH_SIZE"), _per_dispatch(write_csv, "WRITE_SIZE")
+    pg = defaultdict(lambda: [0.0, 0.0, 0])
+    for k, vals in fd.items():
+        per_step = len(vals) // steps
+        wv = wd.get(k, [0.0] * len(vals))
+        for i, v in enumerate(vals):
+            g = group_of(k, i % max(1, per_step))
+            if g is None:
+                continue
+            pg[g][0] += v * 1024.0 * 2.0
+            pg[g][1] += (wv[i] if i < len(wv) else 0.0) * 1024.0
+            pg[g][2] += 1
+    out["per_group"] = {g: {"launches": n // steps, "fetch_MiB_corrected": round(f / n / 2 ** 20, 1), "write_MiB": round(w / n / 2 ** 20, 1),
+                            "hbm_bytes_per_launch": (f + w) / n} for g, (f, w, n) in sorted(pg.items())}
     out["launches_per_step"] = launches // steps
     out["fetch_bytes_per_launch_corrected"] = tot_f / launches
     out["write_bytes_per_launch"] = tot_w / launches
