@@ -18,10 +18,28 @@ void set_last_error(int code, const std::string& msg) { (void)code; g_last_error
 
 // ---- async batcher: restoreBatch's in-flight promises (restorator.js:181-236) coalesced into
 // engine batches of up to max_batch equal-shape images.
+//
+// Data path, ONE host copy per direction: ire_submit copies the caller's pixels straight into the pinned staging slot of
+// the batch being gathered (in the caller's thread: concurrent callers copy concurrently), ire_poll copies from the batch's
+// pinned output to the caller (again in the caller's thread).  Round 2 had three copies per direction on one thread.
+//
+// A slot is FREE -> OPEN (gathering: submits reserve an index and stage into it; the launcher issues each staged image's
+// H2D copy at once, under the previous batch's compute) -> CLOSED (launching) -> INFLIGHT (kernels + D2H enqueued) -> DONE
+// (results in pin_out, waiting for its jobs' ire_poll) -> FREE.  Two threads: the launcher decides when a gathering batch
+// goes (below), the completer waits for the oldest in-flight batch's D2H and completes its jobs.
+//
+// When a batch goes: at once when it is full (the stream runs it behind the previous batch: no bubble); otherwise it keeps
+// gathering while the GPU still computes the previous batch (launching then would only split what a closed-loop caller --
+// 3 jobs per restoreBatch, 5 per worker -- is about to resubmit), and when the GPU is idle after a short bounded linger:
+// kLingerQuietUs after the last arrival, at most kLingerMaxUs after the first.
+struct BatchSlot;
 struct Job {
     int h, w, is_jpeg;
     bool has_scores = false;
-    std::vector<uint8_t> in, out;
+    bool staged = false;              // input bytes are in the slot's pinned buffer (or in `in` on the overflow path)
+    BatchSlot* slot = nullptr;        // where the input was staged and the output will be; null: overflow (no free slot at submit) / evicted
+    int idx = -1;
+    std::vector<uint8_t> in, out;     // overflow input / evicted output only
     double scores[7];
     ire_timings t{};
     int status = -1;  // -1 pending, else ire_status
@@ -38,30 +56,46 @@ struct ire_job { std::shared_ptr<ire::Job> j; };
 struct ire_strips { std::unique_ptr<ire::StripSession> s; ire_engine* owner = nullptr; };
 static std::mutex g_strips_mu;       // guards every ire_engine::sessions list and every ire_strips::s / owner
 
+namespace ire {
+
+constexpr int kSlots = 4;             // gathering | computing | two waiting for their polls
+constexpr int kLingerQuietUs = 250, kLingerMaxUs = 1500;
+
+struct BatchSlot {
+    enum State { FREE, OPEN, CLOSED, INFLIGHT, DONE } state = FREE;
+    uint8_t *pin_in = nullptr, *pin_out = nullptr, *d_in = nullptr, *d_out = nullptr, *pin_jp = nullptr, *d_jp = nullptr;
+    double* pin_sc = nullptr;
+    double* pin_sc_in = nullptr;          // scores the jobs brought along (ire_submit(..., scores, ...))
+    uint8_t has_sc[64] = {};
+    size_t cap = 0;                       // bytes of each image buffer
+    hipEvent_t ev_in = nullptr, ev_c0 = nullptr, ev_c1 = nullptr, ev_out = nullptr;
+    std::vector<std::shared_ptr<Job>> jobs;   // index order = position in the batch
+    int h = 0, w = 0;
+    int h2d_issued = 0;                   // images whose H2D copy is already on the copy-in stream
+    int unread = 0, reading = 0;          // DONE: jobs that have not fetched their output yet / polls copying right now
+    std::chrono::steady_clock::time_point first_arrival, last_arrival;
+    int status = IRE_OK;
+    std::string err;
+};
+
+}  // namespace ire
+
 struct ire_engine {
     std::unique_ptr<ire::Engine> eng;
     // batcher
     std::mutex qmu;
-    std::condition_variable qcv, dcv;
-    std::deque<std::shared_ptr<ire::Job>> queue;
-    std::thread worker;
-    bool stop = false;
+    std::condition_variable qcv, dcv, ccv;     // launcher wake-ups | job completion | completer wake-ups
+    ire::BatchSlot slots[ire::kSlots];
+    std::deque<int> open_order;                // OPEN slots, oldest first
+    std::deque<int> inflight;                  // INFLIGHT slots, launch order
+    std::deque<std::shared_ptr<ire::Job>> overflow;   // submitted while no slot was free: staged by the launcher later
+    int last_launched = -1;
+    std::thread worker, completer;
+    hipStream_t cs = nullptr, os = nullptr;
+    bool stop = false, launcher_done = false;
     int device = 0;
     std::vector<ire_strips*> sessions;     // open strip sessions (g_strips_mu)
-    ~ire_engine() {
-        {
-            std::lock_guard<std::mutex> lk(qmu);
-            stop = true;
-        }
-        qcv.notify_all();
-        if (worker.joinable()) worker.join();
-        std::lock_guard<std::mutex> lk(g_strips_mu);
-        for (ire_strips* s : sessions) {       // invalidate: the StripSession dies with its engine, the caller's shell survives
-            if (eng) { std::lock_guard<std::mutex> lk2(eng->mutex()); s->s.reset(); } else s->s.reset();
-            s->owner = nullptr;
-        }
-        sessions.clear();
-    }
+    ~ire_engine();
 };
 
 namespace ire {
@@ -77,23 +111,6 @@ static void on_stream(Engine& E, hipStream_t s, F&& f) {
     E.leave(s);
 }
 
-// Two-slot pipeline (host feeding is what limits scaling): pinned staging buffers, H2D on a copy-in stream,
-// classify + restore on the engine's main stream, D2H on a copy-out stream; while the GPU works on batch k the thread
-// gathers batch k+1 into the other slot and hands batch k-1's pixels back to its jobs.
-struct BatchSlot {
-    uint8_t *pin_in = nullptr, *pin_out = nullptr, *d_in = nullptr, *d_out = nullptr, *pin_jp = nullptr, *d_jp = nullptr;
-    double* pin_sc = nullptr;
-    double* pin_sc_in = nullptr;          // scores the jobs brought along (ire_submit(..., scores, ...))
-    uint8_t has_sc[64] = {};
-    size_t cap = 0;                       // bytes of each image buffer
-    hipEvent_t ev_in = nullptr, ev_c0 = nullptr, ev_c1 = nullptr, ev_out = nullptr;
-    std::vector<std::shared_ptr<Job>> jobs;
-    int h = 0, w = 0;
-    int status = IRE_OK;
-    std::string err;
-    bool busy = false;
-};
-
 static void slot_reserve(BatchSlot& S, size_t bytes, int max_batch) {
     if (!S.ev_in) {
         IRE_HIP(hipEventCreateWithFlags(&S.ev_in, hipEventDisableTiming));
@@ -107,7 +124,7 @@ static void slot_reserve(BatchSlot& S, size_t bytes, int max_batch) {
     }
     if (bytes <= S.cap) return;
     if (S.pin_in) { (void)hipHostFree(S.pin_in); (void)hipHostFree(S.pin_out); (void)hipFree(S.d_in); (void)hipFree(S.d_out); }
-    S.cap = 0;
+    S.cap = 0; S.pin_in = S.pin_out = S.d_in = S.d_out = nullptr;
     IRE_HIP(hipHostMalloc((void**)&S.pin_in, bytes));
     IRE_HIP(hipHostMalloc((void**)&S.pin_out, bytes));
     IRE_HIP(hipMalloc((void**)&S.d_in, bytes));
@@ -124,116 +141,216 @@ static void slot_free(BatchSlot& S) {
     S = BatchSlot{};
 }
 
-// wait for the slot's batch and hand results (or the error) to its jobs
-static void slot_finish(ire_engine* E, BatchSlot& S) {
-    if (!S.busy) return;
-    ire_timings t{};
-    if (S.status == IRE_OK) {
+// (qmu held) an OPEN slot of this shape with room, else a FREE one opened for it, else -1.  May allocate staging (first use
+// of a shape: once).  A DONE slot nobody is reading is evicted when nothing else is left: its unfetched outputs move to
+// their jobs' own vectors (the extra copy only a caller that lets four batches pile up unpolled ever pays).
+static int slot_for(ire_engine* E, int h, int w) {
+    const int mb = E->eng->max_batch();
+    for (auto it = E->open_order.rbegin(); it != E->open_order.rend(); ++it) {
+        BatchSlot& S = E->slots[*it];
+        if (S.h == h && S.w == w && (int)S.jobs.size() < mb) return *it;
+    }
+    int pick = -1;
+    for (int i = 0; i < kSlots; ++i) if (E->slots[i].state == BatchSlot::FREE) { pick = i; break; }
+    if (pick < 0) {
+        for (int i = 0; i < kSlots && pick < 0; ++i) {
+            BatchSlot& S = E->slots[i];
+            if (S.state != BatchSlot::DONE || S.reading) continue;
+            const size_t ib = (size_t)S.h * S.w * 3;
+            for (auto& j : S.jobs)
+                if (j->slot == &S) { j->out.assign(S.pin_out + ib * j->idx, S.pin_out + ib * (j->idx + 1)); j->slot = nullptr; }
+            S.jobs.clear(); S.unread = 0; S.state = BatchSlot::FREE;
+            pick = i;
+        }
+    }
+    if (pick < 0) return -1;
+    BatchSlot& S = E->slots[pick];
+    {
+        // staging is allocated on first use of a shape, possibly from a caller's thread: leave that thread's current device as it was
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        (void)hipSetDevice(E->device);
+        try { slot_reserve(S, (size_t)h * w * 3 * (size_t)mb, mb); } catch (...) { if (prev >= 0) (void)hipSetDevice(prev); throw; }
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    S.state = BatchSlot::OPEN; S.h = h; S.w = w; S.jobs.clear(); S.h2d_issued = 0; S.unread = S.reading = 0;
+    S.status = IRE_OK; S.err.clear();
+    S.first_arrival = S.last_arrival = std::chrono::steady_clock::now();
+    E->open_order.push_back(pick);
+    return pick;
+}
+
+// (qmu held) reserve the next index of slot si for job j
+static void slot_add(ire_engine* E, int si, const std::shared_ptr<Job>& j) {
+    BatchSlot& S = E->slots[si];
+    j->slot = &S; j->idx = (int)S.jobs.size();
+    S.pin_jp[j->idx] = (uint8_t)j->is_jpeg;
+    S.has_sc[j->idx] = j->has_scores ? 1 : 0;
+    if (j->has_scores) std::memcpy(S.pin_sc_in + 7 * j->idx, j->scores, sizeof(double) * 7);
+    S.jobs.push_back(j);
+    S.last_arrival = std::chrono::steady_clock::now();
+    if (j->idx == 0) S.first_arrival = S.last_arrival;
+}
+
+// (launcher, qmu held) H2D of every image staged so far, in index order, on the copy-in stream: rides under the previous
+// batch's compute.  Returns false on a HIP error (recorded in the slot).
+static void slot_push_h2d(ire_engine* E, BatchSlot& S) {
+    const size_t ib = (size_t)S.h * S.w * 3;
+    int upto = S.h2d_issued;
+    while (upto < (int)S.jobs.size() && S.jobs[upto]->staged) ++upto;
+    if (upto == S.h2d_issued || S.status != IRE_OK) return;
+    const hipError_t rc = hipMemcpyAsync(S.d_in + ib * S.h2d_issued, S.pin_in + ib * S.h2d_issued, ib * (size_t)(upto - S.h2d_issued), hipMemcpyHostToDevice, E->cs);
+    if (rc != hipSuccess) { S.status = IRE_ERR_INTERNAL; S.err = std::string("internal: ") + hipGetErrorString(rc); }
+    S.h2d_issued = upto;
+}
+
+static void complete_jobs(ire_engine* E, BatchSlot& S, const ire_timings& t) {     // qmu held
+    const int n = (int)S.jobs.size();
+    for (int i = 0; i < n; ++i) {
+        Job& j = *S.jobs[i];
+        if (S.status == IRE_OK) { std::memcpy(j.scores, S.pin_sc + 7 * i, sizeof(double) * 7); j.t = t; }
+        else j.slot = nullptr;
+        j.err = S.err;
+        j.status = S.status;
+    }
+    if (S.status == IRE_OK) { S.state = BatchSlot::DONE; S.unread = n; }
+    else { S.jobs.clear(); S.state = BatchSlot::FREE; }
+}
+
+static void launcher_loop(ire_engine* E) {
+    (void)hipSetDevice(E->device);
+    using clk = std::chrono::steady_clock;
+    std::unique_lock<std::mutex> lk(E->qmu);
+    for (;;) {
+        // jobs that found no free slot at submit time: stage them now (this thread copies), oldest first
+        while (!E->overflow.empty()) {
+            std::shared_ptr<Job> j = E->overflow.front();
+            int si = -1;
+            try { si = slot_for(E, j->h, j->w); }
+            catch (const Error& e) { j->status = e.code; j->err = e.msg; E->overflow.pop_front(); E->dcv.notify_all(); continue; }
+            if (si < 0) break;
+            E->overflow.pop_front();
+            slot_add(E, si, j);
+            BatchSlot& S = E->slots[si];
+            std::memcpy(S.pin_in + (size_t)j->h * j->w * 3 * j->idx, j->in.data(), j->in.size());
+            j->in.clear(); j->in.shrink_to_fit();
+            j->staged = true;
+        }
+        if (E->open_order.empty()) {
+            if (E->stop && E->overflow.empty()) break;
+            // (overflow jobs wait for a slot: a poll or the completer frees one and notifies)
+            if (E->overflow.empty()) E->qcv.wait(lk); else E->qcv.wait_for(lk, std::chrono::microseconds(200));
+            continue;
+        }
+        const int si = E->open_order.front();
+        BatchSlot& S = E->slots[si];
+        slot_push_h2d(E, S);
+        const bool full = (int)S.jobs.size() >= E->eng->max_batch();
+        if (!full && !E->stop && S.status == IRE_OK && E->open_order.size() == 1) {
+            bool gpu_busy = false;
+            if (E->last_launched >= 0) {
+                BatchSlot& P = E->slots[E->last_launched];
+                gpu_busy = P.state == BatchSlot::INFLIGHT && hipEventQuery(P.ev_c1) == hipErrorNotReady;
+            }
+            if (gpu_busy) { E->qcv.wait_for(lk, std::chrono::microseconds(100)); continue; }
+            const auto now = clk::now();
+            const auto quiet = std::chrono::duration_cast<std::chrono::microseconds>(now - S.last_arrival).count();
+            const auto age = std::chrono::duration_cast<std::chrono::microseconds>(now - S.first_arrival).count();
+            if (quiet < kLingerQuietUs && age < kLingerMaxUs) { E->qcv.wait_for(lk, std::chrono::microseconds(50)); continue; }
+        }
+        // launch: no more reservations, wait for the copies still running in submitting threads
+        S.state = BatchSlot::CLOSED;
+        E->open_order.pop_front();
+        E->qcv.wait(lk, [&] { for (auto& j : S.jobs) if (!j->staged) return false; return true; });
+        slot_push_h2d(E, S);
+        const int n = (int)S.jobs.size();
+        const size_t ib = (size_t)S.h * S.w * 3;
+        lk.unlock();
+        try {
+            if (S.status != IRE_OK) throw Error{S.status, S.err};
+            IRE_HIP(hipMemcpyAsync(S.d_jp, S.pin_jp, (size_t)n, hipMemcpyHostToDevice, E->cs));
+            IRE_HIP(hipEventRecord(S.ev_in, E->cs));
+            hipStream_t ms = E->eng->main_stream();
+            on_stream(*E->eng, ms, [&] {
+                IRE_HIP(hipStreamWaitEvent(ms, S.ev_in, 0));
+                IRE_HIP(hipEventRecord(S.ev_c0, ms));
+                E->eng->restore_device_mixed(S.d_in, n, S.h, S.w, S.pin_sc_in, S.has_sc, S.d_jp, S.d_out, ms);   // classifies the jobs that brought no scores
+                IRE_HIP(hipMemcpyAsync(S.pin_sc, E->eng->scores_device(), sizeof(double) * 7 * n, hipMemcpyDeviceToHost, ms));
+                IRE_HIP(hipEventRecord(S.ev_c1, ms));
+            });
+            IRE_HIP(hipStreamWaitEvent(E->os, S.ev_c1, 0));
+            IRE_HIP(hipMemcpyAsync(S.pin_out, S.d_out, ib * n, hipMemcpyDeviceToHost, E->os));
+            IRE_HIP(hipEventRecord(S.ev_out, E->os));
+        } catch (const Error& e) { S.status = e.code; S.err = e.msg; }
+        catch (const std::exception& e) { S.status = IRE_ERR_INTERNAL; S.err = std::string("internal: ") + e.what(); }
+        lk.lock();
+        if (S.status == IRE_OK) {
+            S.state = BatchSlot::INFLIGHT;
+            E->inflight.push_back(si);
+            E->last_launched = si;
+            E->ccv.notify_all();
+        } else {
+            // whatever was enqueued before the failure may still touch the slot's buffers: drain before handing the error out
+            lk.unlock(); (void)hipStreamSynchronize(E->cs); (void)hipStreamSynchronize(E->eng->main_stream()); (void)hipStreamSynchronize(E->os); lk.lock();
+            complete_jobs(E, S, ire_timings{});
+            E->dcv.notify_all();
+        }
+    }
+    E->launcher_done = true;
+    E->ccv.notify_all();
+}
+
+static void completer_loop(ire_engine* E) {
+    (void)hipSetDevice(E->device);
+    std::unique_lock<std::mutex> lk(E->qmu);
+    for (;;) {
+        E->ccv.wait(lk, [&] { return !E->inflight.empty() || E->launcher_done; });
+        if (E->inflight.empty()) break;
+        BatchSlot& S = E->slots[E->inflight.front()];
+        lk.unlock();
+        ire_timings t{};
         const hipError_t rc = hipEventSynchronize(S.ev_out);
-        if (rc != hipSuccess) { S.status = IRE_ERR_INTERNAL; S.err = std::string("internal: ") + hipGetErrorString(rc); }
+        int st = IRE_OK; std::string err;
+        if (rc != hipSuccess) { st = IRE_ERR_INTERNAL; err = std::string("internal: ") + hipGetErrorString(rc); }
         else {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, S.ev_c0, S.ev_c1) == hipSuccess) { t.restore_ms = ms; t.total_ms = ms; }
         }
+        lk.lock();
+        if (st != IRE_OK) { S.status = st; S.err = err; }
+        E->inflight.pop_front();
+        complete_jobs(E, S, t);
+        E->dcv.notify_all();
+        E->qcv.notify_all();
     }
-    const size_t ib = (size_t)S.h * S.w * 3;
-    const int n = (int)S.jobs.size();
-    for (int i = 0; i < n; ++i) {          // the pixel copies happen outside the queue lock
-        Job& j = *S.jobs[i];
-        if (S.status == IRE_OK) j.out.assign(S.pin_out + ib * i, S.pin_out + ib * (i + 1));
-    }
-    {
-        std::lock_guard<std::mutex> lk(E->qmu);
-        for (int i = 0; i < n; ++i) {
-            Job& j = *S.jobs[i];
-            if (S.status == IRE_OK) { std::memcpy(j.scores, S.pin_sc + 7 * i, sizeof(double) * 7); j.t = t; }
-            j.err = S.err;
-            j.in.clear(); j.in.shrink_to_fit();
-            j.status = S.status;
-        }
-    }
-    E->dcv.notify_all();
-    S.jobs.clear();
-    S.busy = false;
 }
 
-static void batcher_loop(ire_engine* E) {
-    (void)hipSetDevice(E->device);
-    BatchSlot slots[2];
-    hipStream_t cs = nullptr, os = nullptr;
-    (void)hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
-    (void)hipStreamCreateWithFlags(&os, hipStreamNonBlocking);
-    int p = 0;
-    for (;;) {
-        BatchSlot& S = slots[p];
-        BatchSlot& prev = slots[p ^ 1];
-        {
-            std::unique_lock<std::mutex> lk(E->qmu);
-            // a batch is in flight and nothing new is queued: its jobs are waiting -- finish it before blocking on the queue
-            if (prev.busy && E->queue.empty() && !E->stop) { lk.unlock(); slot_finish(E, prev); lk.lock(); }
-            E->qcv.wait(lk, [&] { return E->stop || !E->queue.empty(); });
-            if (E->stop && E->queue.empty()) break;
-            // coalescing: more submissions of the same shape usually follow at once.  Idle GPU: a 200 us window.  GPU busy with the
-            // previous batch: its jobs come back (and are re-submitted by a closed-loop caller: 3 per restoreBatch, 5 per worker) only
-            // when it ends, so a batch launched now would be whatever trickled in -- keep gathering until this batch is as large as
-            // the one in flight, or that one has finished computing (then nothing is gained by waiting)
-            if ((int)E->queue.size() < E->eng->max_batch()) {
-                if (!prev.busy) {
-                    E->qcv.wait_for(lk, std::chrono::microseconds(200),
-                                    [&] { return E->stop || (int)E->queue.size() >= E->eng->max_batch(); });
-                } else {
-                    const int want = std::min(E->eng->max_batch(), (int)prev.jobs.size());
-                    while (!E->stop && (int)E->queue.size() < want && prev.status == IRE_OK && hipEventQuery(prev.ev_c1) == hipErrorNotReady)
-                        E->qcv.wait_for(lk, std::chrono::microseconds(50));
-                }
-            }
-            S.h = E->queue.front()->h; S.w = E->queue.front()->w;
-            for (auto it = E->queue.begin(); it != E->queue.end() && (int)S.jobs.size() < E->eng->max_batch();) {
-                if ((*it)->h == S.h && (*it)->w == S.w) { S.jobs.push_back(*it); it = E->queue.erase(it); }
-                else ++it;
-            }
-        }
-        const int n = (int)S.jobs.size();
-        const size_t ib = (size_t)S.h * S.w * 3;
-        S.status = IRE_OK; S.err.clear(); S.busy = true;
-        try {
-            slot_reserve(S, ib * (size_t)E->eng->max_batch(), E->eng->max_batch());
-            for (int i = 0; i < n; ++i) {
-                std::memcpy(S.pin_in + ib * i, S.jobs[i]->in.data(), ib); S.pin_jp[i] = (uint8_t)S.jobs[i]->is_jpeg;
-                S.has_sc[i] = S.jobs[i]->has_scores ? 1 : 0;
-                if (S.has_sc[i]) std::memcpy(S.pin_sc_in + 7 * i, S.jobs[i]->scores, sizeof(double) * 7);
-            }
-            IRE_HIP(hipMemcpyAsync(S.d_in, S.pin_in, ib * n, hipMemcpyHostToDevice, cs));
-            IRE_HIP(hipMemcpyAsync(S.d_jp, S.pin_jp, (size_t)n, hipMemcpyHostToDevice, cs));
-            IRE_HIP(hipEventRecord(S.ev_in, cs));
-            {
-                hipStream_t ms = E->eng->main_stream();
-                on_stream(*E->eng, ms, [&] {
-                    IRE_HIP(hipStreamWaitEvent(ms, S.ev_in, 0));
-                    IRE_HIP(hipEventRecord(S.ev_c0, ms));
-                    E->eng->restore_device_mixed(S.d_in, n, S.h, S.w, S.pin_sc_in, S.has_sc, S.d_jp, S.d_out, ms);   // classifies the jobs that brought no scores
-                    IRE_HIP(hipMemcpyAsync(S.pin_sc, E->eng->scores_device(), sizeof(double) * 7 * n, hipMemcpyDeviceToHost, ms));
-                    IRE_HIP(hipEventRecord(S.ev_c1, ms));
-                });
-            }
-            IRE_HIP(hipStreamWaitEvent(os, S.ev_c1, 0));
-            IRE_HIP(hipMemcpyAsync(S.pin_out, S.d_out, ib * n, hipMemcpyDeviceToHost, os));
-            IRE_HIP(hipEventRecord(S.ev_out, os));
-        } catch (const Error& e) { S.status = e.code; S.err = e.msg; }
-        catch (const std::exception& e) { S.status = IRE_ERR_INTERNAL; S.err = std::string("internal: ") + e.what(); }
-        slot_finish(E, prev);       // overlaps with the batch just launched
-        if (S.status != IRE_OK) slot_finish(E, S);
-        p ^= 1;
+}  // namespace ire
+
+ire_engine::~ire_engine() {
+    {
+        std::lock_guard<std::mutex> lk(qmu);
+        stop = true;
     }
-    slot_finish(E, slots[0]);
-    slot_finish(E, slots[1]);
-    (void)hipStreamSynchronize(cs);
-    (void)hipStreamSynchronize(os);
-    slot_free(slots[0]);
-    slot_free(slots[1]);
-    (void)hipStreamDestroy(cs);
-    (void)hipStreamDestroy(os);
+    qcv.notify_all();
+    if (worker.joinable()) worker.join();        // launches what is still gathered, then exits
+    ccv.notify_all();
+    if (completer.joinable()) completer.join();  // completes every batch in flight
+    if (eng) {
+        (void)hipSetDevice(device);
+        if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
+        if (os) { (void)hipStreamSynchronize(os); (void)hipStreamDestroy(os); }
+        for (auto& S : slots) ire::slot_free(S);
+    }
+    std::lock_guard<std::mutex> lk(g_strips_mu);
+    for (ire_strips* s : sessions) {       // invalidate: the StripSession dies with its engine, the caller's shell survives
+        if (eng) { std::lock_guard<std::mutex> lk2(eng->mutex()); s->s.reset(); } else s->s.reset();
+        s->owner = nullptr;
+    }
+    sessions.clear();
 }
+
+namespace ire {
 
 template <typename F>
 static int guarded(F&& f) {
@@ -481,7 +598,9 @@ int ire_get_stats(ire_engine* e, ire_engine_stats* out) {
             E.get_stats(out);
         }
         std::lock_guard<std::mutex> lk(e->qmu);
-        out->queue_depth = (int32_t)e->queue.size();
+        int depth = (int)e->overflow.size();
+        for (int si : e->open_order) depth += (int)e->slots[si].jobs.size();
+        out->queue_depth = depth;
     });
 }
 
@@ -494,11 +613,31 @@ int ire_submit(ire_engine* e, const uint8_t* rgb, int h, int w, int is_jpeg, con
         auto j = std::make_shared<Job>();
         j->h = h; j->w = w; j->is_jpeg = is_jpeg ? 1 : 0;
         if (scores) { std::memcpy(j->scores, scores, sizeof(double) * 7); j->has_scores = true; }
-        j->in.assign(rgb, rgb + (size_t)h * w * 3);
+        const size_t ib = (size_t)h * w * 3;
+        uint8_t* dst = nullptr;
         {
             std::lock_guard<std::mutex> lk(e->qmu);
-            if (!e->worker.joinable()) e->worker = std::thread(batcher_loop, e);
-            e->queue.push_back(j);
+            if (!e->worker.joinable()) {
+                int prev = -1;
+                (void)hipGetDevice(&prev);
+                (void)hipSetDevice(e->device);
+                IRE_HIP(hipStreamCreateWithFlags(&e->cs, hipStreamNonBlocking));
+                IRE_HIP(hipStreamCreateWithFlags(&e->os, hipStreamNonBlocking));
+                if (prev >= 0) (void)hipSetDevice(prev);
+                e->worker = std::thread(launcher_loop, e);
+                e->completer = std::thread(completer_loop, e);
+            }
+            const int si = e->overflow.empty() ? slot_for(e, h, w) : -1;     // (jobs already overflowing keep their order)
+            if (si >= 0) { slot_add(e, si, j); dst = e->slots[si].pin_in + ib * j->idx; }
+        }
+        if (dst) {
+            std::memcpy(dst, rgb, ib);                 // the ONE host copy of the input: caller's buffer -> pinned slot, in the caller's thread
+            std::lock_guard<std::mutex> lk(e->qmu);
+            j->staged = true;
+        } else {
+            j->in.assign(rgb, rgb + ib);               // every slot is busy: keep the pixels until the launcher finds one
+            std::lock_guard<std::mutex> lk(e->qmu);
+            e->overflow.push_back(j);
         }
         e->qcv.notify_all();
         *job_out = new ire_job{j};
@@ -510,19 +649,30 @@ int ire_poll(ire_engine* e, ire_job* job, int timeout_ms, uint8_t* out_rgb, doub
         eng(e);
         if (!job || !job->j) fail(IRE_ERR_INVALID_INPUT, "invalid job handle");
         std::shared_ptr<Job> j = job->j;
+        BatchSlot* S = nullptr;
         {
             std::unique_lock<std::mutex> lk(e->qmu);
             auto done = [&] { return j->status >= 0; };
             if (timeout_ms < 0) e->dcv.wait(lk, done);
             else if (!e->dcv.wait_for(lk, std::chrono::milliseconds(timeout_ms), done))
                 fail(IRE_ERR_TIMEOUT, "timeout: job still pending");
+            S = j->slot;
+            if (S) S->reading += 1;        // the slot cannot be recycled (or evicted) while this thread copies from it
         }
         const int st = j->status;
         const std::string err = j->err;
         if (st == IRE_OK) {
-            if (out_rgb) std::memcpy(out_rgb, j->out.data(), j->out.size());
+            const size_t ib = (size_t)j->h * j->w * 3;
+            // the ONE host copy of the output: pinned slot -> caller's buffer, in the caller's thread
+            if (out_rgb) std::memcpy(out_rgb, S ? S->pin_out + ib * j->idx : j->out.data(), ib);
             if (scores_out) std::memcpy(scores_out, j->scores, sizeof(double) * 7);
             if (t) *t = j->t;
+        }
+        if (S) {
+            std::lock_guard<std::mutex> lk(e->qmu);
+            S->reading -= 1; S->unread -= 1;
+            j->slot = nullptr;
+            if (S->unread == 0 && S->state == BatchSlot::DONE) { S->jobs.clear(); S->state = BatchSlot::FREE; e->qcv.notify_all(); }
         }
         delete job;
         if (st != IRE_OK) fail(st, err);

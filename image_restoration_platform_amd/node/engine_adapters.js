@@ -90,6 +90,7 @@ let jobCounter = 0;
 function createEngineRestorer(opts) {
   const engine = opts.engine;
   const codec = opts.codec || defaultCodec();
+  const timeoutMs = opts.timeoutMs || 120000;     // the reference's provider timeout class (geminiClient.js: a hung call surfaces as TIMEOUT)
   return {
     async restoreImage(args) {
       const images = args.images;
@@ -114,8 +115,9 @@ function createEngineRestorer(opts) {
           // the conditioning scores are those of the image itself (what analyze() reports), never of its replicate-padded copy
           scores = Float64Array.from((await engine.addon.classifyAsync(engine.handle, d.data, 1, d.height, d.width, flags)).scores.slice(0, 7));
         }
-        return scores ? engine.addon.restoreAsync(engine.handle, p.data, 1, p.height, p.width, flags, scores)   // scores known: not classified again
-                      : engine.addon.restoreAsync(engine.handle, p.data, 1, p.height, p.width, flags);          // classifies inside
+        // scores known: not classified again; null: classifies inside.  timeoutMs bounds the wait for the engine's batch: a wedged
+        // engine rejects with code ENGINE_TIMEOUT ("timeout: ..." -> TIMEOUT in _classifyError) instead of hanging the promise
+        return engine.addon.restoreAsync(engine.handle, p.data, 1, p.height, p.width, flags, scores || null, timeoutMs);
       });
       const restored = (await Promise.all(pending)).map((r) => r.pixels);
       let pixels = restored[0];

@@ -2,19 +2,28 @@
 //
 // BASELINE.json's north_star names node-ffi-napi; that module is not installable offline, so
 // this shim is the guaranteed path (N-API v8 headers ship with node: /usr/include/node/node_api.h) and
-// node/ire_ffi.mjs keeps the equivalent ffi-napi declaration.  Every engine call runs as napi async work
-// on the libuv pool and resolves a Promise, because the reference's seams are asynchronous
-// (classifier.analyze / geminiClient.restoreImage are awaited: restorator.js:59-94) and must tolerate >= 8
-// calls in flight.  libire.so is dlopen'ed at run time so the addon builds and loads on GPU-less hosts;
+// node/ire_ffi.mjs keeps the equivalent ffi-napi declaration.  Every engine call resolves a Promise, because
+// the reference's seams are asynchronous (classifier.analyze / geminiClient.restoreImage are awaited:
+// restorator.js:59-94) and must tolerate >= 8 calls in flight.  The short synchronous calls (classify, fuse,
+// preprocess, multi-image restore) run as napi async work on the libuv pool.  A single-image restore --
+// the reference's unit of work -- is queued with the engine's batcher on the JS thread (ire_submit: one copy,
+// Buffer -> pinned staging) and waited for by this addon's OWN waiter threads (ire_poll with the job's
+// timeout, writing straight into the result Buffer), completed through a thread-safe function: the libuv
+// pool (4 threads shared with fs / dns / zlib / crypto) is never parked for the length of a GPU batch, and
+// a wedged engine rejects with ENGINE_TIMEOUT so the worker's retry -> DLQ path is reached.  libire.so is dlopen'ed at run time so the addon builds and loads on GPU-less hosts;
 // without a device ire_init fails and the rejection text contains "service unavailable".
 //
 // Build: g++ -O2 -shared -fPIC -I/usr/include/node ire_napi.cc -o ire_napi.node -ldl
 #include <dlfcn.h>
 #include <node_api.h>
 
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ire.h"
@@ -73,8 +82,25 @@ struct Job {
     int status = 0;
     std::string err;
     napi_deferred deferred;
-    napi_async_work work;
+    napi_async_work work = nullptr;
+    // single-image restore through the batcher (waiter threads): the result Buffer is created up front on the JS thread and
+    // ire_poll writes into it; the engine handle is referenced so that it cannot be finalized under a pending job
+    int timeout_ms = 120000;
+    uint8_t* out_ptr = nullptr;
+    napi_ref out_ref = nullptr, eng_ref = nullptr;
 };
+
+// ---- waiter threads + thread-safe completion (single-image restores) --------------------------------
+struct Waiters {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<struct Job*> q;
+    napi_threadsafe_function tsfn = nullptr;
+    int pending = 0;              // JS thread only: jobs handed to the waiters and not completed yet (keeps the tsfn referenced)
+    bool started = false;
+};
+Waiters* W = nullptr;             // leaked on purpose: detached threads may outlive static destruction
+constexpr int kWaiterThreads = 4;
 
 void execute(napi_env, void* data) {
     Job* j = (Job*)data;
@@ -84,13 +110,8 @@ void execute(napi_env, void* data) {
             j->status = g.classify(j->eng, j->in.data(), j->n, j->h, j->w, 3 * j->w, j->jpeg.data(), j->scores.data(), j->labels.data());
             break;
         case Job::RESTORE:
-            j->out.resize((size_t)j->n * j->h * j->w * 3);
-            if (j->queued) {          // the pool thread only waits: every in-flight job is already queued, so they coalesce
-                j->scores.resize(7);
-                j->status = g.poll(j->eng, j->queued, -1, j->out.data(), j->scores.data(), &j->t);
-            } else {
-                j->status = g.restore(j->eng, j->in.data(), j->n, j->h, j->w, j->has_scores ? j->scores.data() : nullptr, j->jpeg.data(), j->out.data(), &j->t);
-            }
+            j->out.resize((size_t)j->n * j->h * j->w * 3);      // (n > 1 only: single images go through the batcher + waiter threads)
+            j->status = g.restore(j->eng, j->in.data(), j->n, j->h, j->w, j->has_scores ? j->scores.data() : nullptr, j->jpeg.data(), j->out.data(), &j->t);
             break;
         case Job::PREPROCESS:
             j->out.resize((size_t)j->out_h * j->out_w * 3);
@@ -104,8 +125,7 @@ void execute(napi_env, void* data) {
     if (j->status != 0) j->err = g.last_error();   // thread-local: read on the worker thread
 }
 
-void complete(napi_env env, napi_status, void* data) {
-    Job* j = (Job*)data;
+void finish(napi_env env, Job* j) {
     if (j->status != 0) {
         napi_value msg, err, code;
         napi_create_string_utf8(env, j->err.c_str(), NAPI_AUTO_LENGTH, &msg);
@@ -127,7 +147,8 @@ void complete(napi_env env, napi_status, void* data) {
             napi_set_named_property(env, res, "labels", ta);
         } else {
             napi_value buf; void* p;
-            napi_create_buffer_copy(env, j->out.size(), j->out.data(), &p, &buf);
+            if (j->out_ref) napi_get_reference_value(env, j->out_ref, &buf);       // ire_poll wrote into it: no further copy
+            else napi_create_buffer_copy(env, j->out.size(), j->out.data(), &p, &buf);
             napi_set_named_property(env, res, "pixels", buf);
             napi_value ms; napi_create_double(env, j->t.restore_ms, &ms); napi_set_named_property(env, res, "restore_ms", ms);
             napi_create_double(env, j->t.classify_ms, &ms); napi_set_named_property(env, res, "classify_ms", ms);
@@ -152,13 +173,48 @@ void complete(napi_env env, napi_status, void* data) {
         }
         napi_resolve_deferred(env, j->deferred, res);
     }
-    napi_delete_async_work(env, j->work);
+    if (j->out_ref) napi_delete_reference(env, j->out_ref);
+    if (j->eng_ref) napi_delete_reference(env, j->eng_ref);
+    if (j->work) napi_delete_async_work(env, j->work);
     delete j;
+}
+void complete(napi_env env, napi_status, void* data) { finish(env, (Job*)data); }
+
+// thread-safe function body (JS thread): one waited-for job is done
+void complete_ts(napi_env env, napi_value, void*, void* data) {
+    if (!env) return;                 // the environment is going away: nothing to resolve
+    finish(env, (Job*)data);
+    if (--W->pending == 0) napi_unref_threadsafe_function(env, W->tsfn);      // idle: do not keep the event loop alive
+}
+void waiter_main() {
+    for (;;) {
+        Job* j;
+        {
+            std::unique_lock<std::mutex> lk(W->mu);
+            W->cv.wait(lk, [] { return !W->q.empty(); });
+            j = W->q.front(); W->q.pop_front();
+        }
+        j->scores.resize(7);
+        j->status = g.poll(j->eng, j->queued, j->timeout_ms, j->out_ptr, j->scores.data(), &j->t);
+        if (j->status != 0) j->err = g.last_error();          // thread-local: read on this thread
+        napi_call_threadsafe_function(W->tsfn, j, napi_tsfn_blocking);
+    }
+}
+bool waiters_start(napi_env env) {
+    if (!W) W = new Waiters();
+    if (W->started) return true;
+    napi_value name;
+    napi_create_string_utf8(env, "ire-restore-done", NAPI_AUTO_LENGTH, &name);
+    if (napi_create_threadsafe_function(env, nullptr, nullptr, name, 0, 1, nullptr, nullptr, nullptr, complete_ts, &W->tsfn) != napi_ok) return false;
+    napi_unref_threadsafe_function(env, W->tsfn);
+    for (int i = 0; i < kWaiterThreads; ++i) std::thread(waiter_main).detach();
+    W->started = true;
+    return true;
 }
 
 // submit(kind, engineHandle(external), pixels Buffer, n, h, w, jpegFlags Buffer|null, noise) -> Promise
 napi_value submit(napi_env env, napi_callback_info info, Job::Kind kind) {
-    size_t argc = 7; napi_value argv[7];
+    size_t argc = 8; napi_value argv[8];
     napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
     if (argc < 5) { throw_err(env, "invalid arguments"); return nullptr; }
     void* eng = nullptr;
@@ -183,7 +239,8 @@ napi_value submit(napi_env env, napi_callback_info info, Job::Kind kind) {
         delete j;
         return promise;
     }
-    j->in.assign((uint8_t*)data, (uint8_t*)data + need);       // the caller's Buffer is not retained
+    const bool batched = kind == Job::RESTORE && j->n == 1;    // through ire_submit: the engine copies the Buffer itself (one copy)
+    if (!batched) j->in.assign((uint8_t*)data, (uint8_t*)data + need);       // the caller's Buffer is not retained
     j->jpeg.assign(j->n, 1);
     if (argc > 5) {
         void* jd; size_t jl;
@@ -203,13 +260,16 @@ napi_value submit(napi_env env, napi_callback_info info, Job::Kind kind) {
             }
         }
     }
-    if (kind == Job::RESTORE && j->n == 1) {
+    if (batched) {
         // single-image jobs (the reference's unit of work: restorator.js:198-211) go through the engine's batcher: queue NOW,
-        // on the JS thread, so that every in-flight promise is in the queue before any pool thread blocks in ire_poll
-        const int rc = g.submit(j->eng, j->in.data(), j->h, j->w, j->jpeg[0], j->has_scores ? j->scores.data() : nullptr, &j->queued);
+        // on the JS thread (ire_submit copies Buffer -> pinned staging: the only copy of the input), so that every in-flight
+        // promise is in the batcher before anything waits; the waiter threads then ire_poll with the job's timeout
+        if (argc > 7) { const int64_t tmo = get_i64(env, argv[7]); if (tmo > 0) j->timeout_ms = (int)(tmo > 0x7fffffff ? 0x7fffffff : tmo); }
+        int rc = waiters_start(env) ? 0 : 4;
+        if (rc == 0) rc = g.submit(j->eng, (const uint8_t*)data, j->h, j->w, j->jpeg[0], j->has_scores ? j->scores.data() : nullptr, &j->queued);
         if (rc != 0) {
             napi_value msg, err, code;
-            napi_create_string_utf8(env, g.last_error(), NAPI_AUTO_LENGTH, &msg);
+            napi_create_string_utf8(env, W && W->started ? g.last_error() : "internal: cannot create the completion function", NAPI_AUTO_LENGTH, &msg);
             napi_create_error(env, nullptr, msg, &err);
             const char* codes[] = {"", "ENGINE_INVALID_INPUT", "ENGINE_TIMEOUT", "ENGINE_UNAVAILABLE", "ENGINE_INTERNAL"};
             napi_create_string_utf8(env, codes[rc >= 1 && rc <= 4 ? rc : 4], NAPI_AUTO_LENGTH, &code);
@@ -218,7 +278,18 @@ napi_value submit(napi_env env, napi_callback_info info, Job::Kind kind) {
             delete j;
             return promise;
         }
-        std::vector<uint8_t>().swap(j->in);     // the engine copied it
+        napi_value outbuf; void* op = nullptr;
+        napi_create_buffer(env, need, &op, &outbuf);               // the result: ire_poll writes into it from a waiter thread
+        j->out_ptr = (uint8_t*)op;
+        napi_create_reference(env, outbuf, 1, &j->out_ref);
+        napi_create_reference(env, argv[0], 1, &j->eng_ref);     // the engine outlives its pending jobs
+        if (W->pending++ == 0) napi_ref_threadsafe_function(env, W->tsfn);
+        {
+            std::lock_guard<std::mutex> lk(W->mu);
+            W->q.push_back(j);
+        }
+        W->cv.notify_one();
+        return promise;
     }
     napi_value name;
     napi_create_string_utf8(env, "ire", NAPI_AUTO_LENGTH, &name);

@@ -20,12 +20,26 @@ print(f"ire_restore (host numpy, bs {B} @{S}^2): {N * B / dt:.1f} img/s, {1e3 * 
 jobs = [eng.submit(x[i % B]) for i in range(16)]
 for j in jobs:
     eng.poll(j)
+b0 = eng.stats()["batches"]
 t0 = time.perf_counter()
 jobs = [eng.submit(x[i % B]) for i in range(64)]
 for j in jobs:
     eng.poll(j)
 dt = time.perf_counter() - t0
-print(f"ire_submit/ire_poll (64 single-image jobs, coalesced): {64 / dt:.1f} img/s")
+print(f"ire_submit/ire_poll (64 single-image jobs queued at once, coalesced): {64 / dt:.1f} img/s, {eng.stats()['batches'] - b0} engine batches")
+import collections
+for inflight in (3, 5, 8, 16):          # closed loop from ONE thread: poll the oldest, submit the next
+    b0 = eng.stats()["batches"]
+    t0 = time.perf_counter()
+    q = collections.deque()
+    for i in range(64):
+        if len(q) == inflight:
+            eng.poll(q.popleft())
+        q.append(eng.submit(x[i % B]))
+    while q:
+        eng.poll(q.popleft())
+    dt = time.perf_counter() - t0
+    print(f"ire_submit/ire_poll closed loop, {inflight} in flight: {64 / dt:.1f} img/s, {eng.stats()['batches'] - b0} engine batches per 64 jobs")
 
 # the Node seams (N-API shim -> ire_submit / ire_poll): in-flight single-image restoreImage calls, raw codec
 import json, shutil, subprocess
@@ -36,5 +50,9 @@ if shutil.which("node"):
     for inflight in (3, 5, 8):
         r = subprocess.run(["node", nd, weights.ensure_default(0), str(S), str(inflight), "64"], capture_output=True, text=True, timeout=600)
         j = json.loads(r.stdout.strip().splitlines()[-1])
-        print(f"Node restoreImage, {inflight} in flight @{S}^2 (copy + base64-free raw codec): {j.get('imagesPerSec', 0):.1f} img/s, "
-              f"{j.get('engineBatches')} engine batches for {j.get('total')} jobs")
+        if "fatal" in j:
+            print("Node:", j)
+            continue
+        print(f"Node, {inflight} in flight @{S}^2: shim alone (addon.restoreAsync) {j['shim']['imagesPerSec']:.1f} img/s, {j['shim']['engineBatches']} engine batches per {j['total']} jobs; "
+              f"whole seam (restoreImage: raw codec + base64 string) {j['seam']['imagesPerSec']:.1f} img/s, {j['seam']['engineBatches']} batches "
+              f"(V8 base64 of one raw image: {j['jsThreadBase64MsPerJob']:.2f} ms on the JS thread = a {j['jsThreadBound']:.0f} img/s bound by itself)")
