@@ -20,7 +20,8 @@ SOURCES = [
     ("conv_rb.hip", (["-DIRE_RB_ABLATE"] if os.environ.get("IRE_RB_ABLATE") else []) +
      (["-DIRE_RB_NGP64=" + os.environ["IRE_RB_NGP64"]] if os.environ.get("IRE_RB_NGP64") else [])),
     ("conv_w4.hip", (["-DIRE_W4_STAMPS"] if os.environ.get("IRE_RB_ABLATE") else []) +
-     (["-DIRE_W4_TICKS"] if os.environ.get("IRE_RB_ABLATE") == "2" else [])),
+     (["-DIRE_W4_TICKS"] if os.environ.get("IRE_RB_ABLATE") == "2" else []) +
+     (["-DW4_TEPI=" + os.environ["IRE_W4_TEPI"]] if os.environ.get("IRE_W4_TEPI") else [])),
     ("conv_up.hip", (["-DIRE_UP_ABL=" + os.environ["IRE_UP_ABL"]] if os.environ.get("IRE_UP_ABL") else []) +
      (["-DIRE_UP_D=" + os.environ["IRE_UP_D"]] if os.environ.get("IRE_UP_D") else [])),
     ("conv_down.hip", []),

@@ -621,8 +621,12 @@ int ire_submit(ire_engine* e, const uint8_t* rgb, int h, int w, int is_jpeg, con
                 int prev = -1;
                 (void)hipGetDevice(&prev);
                 (void)hipSetDevice(e->device);
-                IRE_HIP(hipStreamCreateWithFlags(&e->cs, hipStreamNonBlocking));
-                IRE_HIP(hipStreamCreateWithFlags(&e->os, hipStreamNonBlocking));
+                if (!e->cs) IRE_HIP(hipStreamCreateWithFlags(&e->cs, hipStreamNonBlocking));
+                if (!e->os) IRE_HIP(hipStreamCreateWithFlags(&e->os, hipStreamNonBlocking));
+                // staging for every slot now, at this first shape (pinning 4 x 2 x max_batch images takes tens of ms): the
+                // first job pays it once, instead of three later jobs paying it one slot at a time in the middle of a stream
+                try { for (auto& S : e->slots) slot_reserve(S, ib * (size_t)e->eng->max_batch(), e->eng->max_batch()); }
+                catch (...) { if (prev >= 0) (void)hipSetDevice(prev); throw; }
                 if (prev >= 0) (void)hipSetDevice(prev);
                 e->worker = std::thread(launcher_loop, e);
                 e->completer = std::thread(completer_loop, e);

@@ -21,6 +21,10 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef W4_TEPI
+#define W4_TEPI 1      // 0: the direct epilogue of round 2 (build-time A/B: IRE_W4_TEPI=0)
+#endif
+
 namespace ire {
 
 namespace {
@@ -90,7 +94,9 @@ struct W4Cfg {
     static constexpr int W_ITERS = (W_CHUNKS + THREADS - 1) / THREADS;
     static constexpr int W_BASE = 2 * IN_BYTES;                // in[2] | w[3]
     static constexpr int MAIN_BYTES = W_BASE + 3 * W_BYTES;
-    static constexpr int RED_BYTES = WAVES * 8 * 2 * 4;        // [waves][8 slots of 16 couts][sum, sumsq]
+    static constexpr int RED_BYTES = 2 * WAVES * 16 * 2 * 4;   // [item parity][waves][16 chunks of 8 couts][sum, sumsq]  (old epilogue: [waves][8 slots of 16 couts][2])
+    static constexpr int PATCH_BYTES = 16 * 256;               // line-coalesced epilogue: a wave's transpose patch (16 pixels x 128 couts) inside the stage's dead weight slab
+    static_assert(FP8 || WAVES * PATCH_BYTES <= W4_NSTEPS * 2 * NT * EB, "the patches live in one weight slab");
     static constexpr int BIAS_BYTES = 256 * 4;
     static constexpr int COEF_BYTES = WAVES * 128;             // FUSED: per wave, 16 channels x (A, B) of the stage being staged
     static constexpr int SCALE_BYTES = FP8 ? 256 * 4 : 0;      // FP8: per-cout output scale
@@ -285,6 +291,30 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
     unsigned offs[C::MT];
     bool inb[C::MT];
     int cout0_e = 0;
+    // ---- line-coalesced epilogue (TEPI): the accumulator layout (lane = pixel, 8 couts per register group) makes every global
+    // instruction of the direct epilogue touch 32 pixels x 32 B -- 32 different lines, ~3 cycles each through the L1 (stamps,
+    // profiles/r03_experiments.md: the RB2 epilogue was 23 800 ticks per item, 3.2 stages' worth, RB1's 11 000).  Here a wave
+    // transposes 16 pixels x 128 couts at a time through a 4-KB patch of the stage's dead weight slab (XOR-swizzled: conflict-free
+    // both ways) and reads / writes global memory in whole 256-B pixel runs: 1 KB contiguous per instruction.
+    constexpr bool TEPI = W4_TEPI && WAVES == 8 && !FP8 && !(DBG & 64);        // (the same-rate fp8 fallback has half-size slabs: direct epilogue)
+    unsigned toffs[C::MT];        // byte offset of (this lane's read-back pixel at q = 0, k = 0; its chunk c = lane & 15) in the output image
+    bool trow[C::MT];
+    int tcol0 = 0;
+    uint4 rvt[3][4];              // residual rows of pass (m, q) in slot pass % 3, read-back layout: 4 loads of 1 KB each
+    auto load_resid_pass = [&](int pass, uint4 (&dst)[4]) {
+        if constexpr (RESID) {
+            char* rbase = const_cast<char*>(reinterpret_cast<const char*>(a.resid)) + (size_t)sq0.it.img * a.Hout * a.Wout * a.cout * 2;
+            const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(rbase, 0, a.Hout * a.Wout * a.cout * 2, 0x00020000);
+            const int m = pass >> 1, q = pass & 1;
+            const unsigned cstep = (unsigned)a.cout * 8u;          // bytes per 4 pixels
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool ok = trow[m] && tcol0 + 16 * q + 4 * k < a.Wout;
+                const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ok ? toffs[m] + (unsigned)(4 * q + k) * cstep : 0xffffffffu, 0, 0);
+                dst[k] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+        }
+    };
     auto load_resid = [&](int g, uint4 (&dst)[C::MT]) {
         if constexpr (RESID) {
             const char* rbase = reinterpret_cast<const char*>(a.resid) + (size_t)sq0.it.img * a.Hout * a.Wout * a.cout * 2;
@@ -294,6 +324,22 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
         }
     };
     auto epi_prefetch = [&]() {
+        if constexpr (TEPI) {
+            const W4Item it = sq0.it;
+            int l_e = lane, w_e = wave;
+            asm volatile("" : "+v"(l_e), "+v"(w_e));
+            cout0_e = it.nb * NT;
+            const int oyb = it.ty * W4_TH + w_e * C::MT;
+            tcol0 = it.tx * W4_TW + (l_e >> 4);
+#pragma unroll
+            for (int m = 0; m < C::MT; ++m) {
+                const int oy = oyb + m;
+                trow[m] = oy < a.Hout;
+                toffs[m] = ((unsigned)((min(oy, a.Hout - 1) * a.Wout + tcol0) * a.cout + cout0_e + 8 * (l_e & 15)) << 1);
+            }
+            load_resid_pass(0, rvt[0]);       // before the stage's MFMAs (k-steps 0..3 carry no other VMEM): landed when the epilogue starts
+            return;
+        }
         const W4Item it = sq0.it;
         int r_e = r, h_e = h, w_e = wave;
         asm volatile("" : "+v"(r_e), "+v"(h_e), "+v"(w_e));
@@ -371,7 +417,10 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
                     asm volatile("" : "+v"(cnext.x), "+v"(cnext.y), "+v"(cnext.z), "+v"(cnext.w));
                     stage_coeffs(cnext);
                 }
-                if constexpr (LAST && RESID) {      // landed as well: tell the compiler, or it re-waits with its own (short) count
+                if constexpr (LAST && RESID && TEPI) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(rvt[0][k].x), "+v"(rvt[0][k].y), "+v"(rvt[0][k].z), "+v"(rvt[0][k].w));
+                } else if constexpr (LAST && RESID) {      // landed as well: tell the compiler, or it re-waits with its own (short) count
 #pragma unroll
                     for (int g = 0; g + 1 < RD; ++g)
 #pragma unroll
@@ -561,6 +610,99 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
             }
         }
     };
+    // ---- TEPI: line-coalesced epilogue through wave-private LDS patches (see the note at `TEPI`) ---------------------------------
+    int st_img = -1, st_tile = 0, st_cout0 = 0, st_par = 0, red_par = 0;
+    auto flush_stats = [&]() {          // GroupNorm partials of the item that finished before the last stage barrier: 8 waves x 16 chunk slots -> groups
+        if (st_img < 0) return;
+        const int G = a.group_size, cpg = G >> 3, ngl = NT / G;      // chunks of 8 couts per group (2 or 4), groups in the item
+        if (a.stats && tid < ngl) {
+            const float* rd = red + st_par * (WAVES * 32);
+            float sv = 0.f, qv = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < cpg) { sv += rd[(w * 16 + tid * cpg + k) * 2 + 0]; qv += rd[(w * 16 + tid * cpg + k) * 2 + 1]; }
+            float* st = a.stats + (((size_t)st_img * tiles_per_img + st_tile) * 8 + st_cout0 / G + tid) * 2;
+            st[0] = sv; st[1] = qv;
+        }
+        st_img = -1;
+    };
+    auto epilogue_t = [&]() {
+        const W4Item it = sq0.it;
+        int h_e = h, l_e = lane;
+        asm volatile("" : "+v"(h_e), "+v"(l_e));
+        const int cout0 = cout0_e;
+        // every wave is past its last fragment read of the stage: the slab becomes eight wave-private patches
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        stamp(8);
+        if constexpr (RESID) { load_resid_pass(1, rvt[1]); load_resid_pass(2, rvt[2]); }      // into the registers the fragments just freed; pass p + 3 follows pass p
+        unsigned char* patch = smem + C::W_BASE + widx * C::W_BYTES + wave * C::PATCH_BYTES;
+        char* obase = reinterpret_cast<char*>(a.out) + (size_t)it.img * a.Hout * a.Wout * a.cout * 2;
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.Hout * a.Wout * a.cout * 2, 0x00020000);
+        const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+        const int r16 = l_e & 15, qh = (l_e >> 4) & 1;                    // writer: pixel r = 16 qh + r16 of the row, half h
+        const int pq = l_e >> 4, cc_r = l_e & 15;                         // reader: pixel 4 k + pq of the half-row, chunk cc_r (8 couts)
+        const unsigned cstep = (unsigned)a.cout * 8u;
+        float ssum = 0.f, qsum = 0.f;
+#pragma unroll
+        for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (qh == q) {
+#pragma unroll
+                    for (int g = 0; g < NTL * 2; ++g) {
+                        const int j = g >> 1, pp = g & 1;
+                        const f32x16_t& c = acc[m][j];
+                        u32x4_t wv;
+                        if constexpr (FP8) {
+                            const float* sl = reinterpret_cast<const float*>(smem + C::MAIN_BYTES + C::RED_BYTES + C::BIAS_BYTES + C::COEF_BYTES);
+                            const float4 s0 = *reinterpret_cast<const float4*>(sl + cout0 + j * 32 + 16 * pp + 8 * h_e);
+                            const float4 s1 = *reinterpret_cast<const float4*>(sl + cout0 + j * 32 + 16 * pp + 8 * h_e + 4);
+                            wv = u32x4_t{w4_pack(c[8 * pp + 0] * s0.x, c[8 * pp + 1] * s0.y), w4_pack(c[8 * pp + 2] * s0.z, c[8 * pp + 3] * s0.w),
+                                         w4_pack(c[8 * pp + 4] * s1.x, c[8 * pp + 5] * s1.y), w4_pack(c[8 * pp + 6] * s1.z, c[8 * pp + 7] * s1.w)};
+                        } else {
+                            wv = u32x4_t{w4_pack(c[8 * pp + 0], c[8 * pp + 1]), w4_pack(c[8 * pp + 2], c[8 * pp + 3]),
+                                         w4_pack(c[8 * pp + 4], c[8 * pp + 5]), w4_pack(c[8 * pp + 6], c[8 * pp + 7])};
+                        }
+                        const int cc = 2 * g + h_e;                       // chunk of the pixel's 128-cout run: couts 8 cc .. 8 cc + 7
+                        *reinterpret_cast<u32x4_t*>(patch + r16 * 256 + ((cc ^ r16) << 4)) = wv;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int p = 4 * k + pq;
+                    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(patch + p * 256 + ((cc_r ^ p) << 4));
+                    unsigned w[4] = {v.x, v.y, v.z, v.w};
+                    if constexpr (RESID) {
+                        const uint4 rr = rvt[(2 * m + q) % 3][k];
+                        const unsigned rw[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) w[d] = w4_pack(w4_lo(w[d]) + w4_lo(rw[d]), w4_hi(w[d]) + w4_hi(rw[d]));
+                    }
+                    float s1 = 0.f, q1 = 0.f;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const bf16x2_t bv = __builtin_bit_cast(bf16x2_t, w[d]);
+                        s1 = __builtin_amdgcn_fdot2_f32_bf16(bv, ones, s1, false);
+                        q1 = __builtin_amdgcn_fdot2_f32_bf16(bv, bv, q1, false);
+                    }
+                    const bool ok = trow[m] && tcol0 + 16 * q + 4 * k < a.Wout && (!(DBG & 4) || w[0] == 0x12345678u);
+                    ssum += ok ? s1 : 0.f; qsum += ok ? q1 : 0.f;
+                    const u32x4_t o4 = {w[0], w[1], w[2], w[3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(o4, orsrc, ok ? toffs[m] + (unsigned)(4 * q + k) * cstep : 0xffffffffu, 0, 0);
+                }
+                if constexpr (RESID) { if (2 * m + q + 3 < 2 * C::MT) load_resid_pass(2 * m + q + 3, rvt[(2 * m + q) % 3]); }
+            }
+        stamp(9);
+        // this lane's chunk cc_r over its 16 read-backs; the other three lanes with the same chunk sit 16, 32, 48 lanes away
+        ssum = w4_swap16_add(ssum); qsum = w4_swap16_add(qsum);
+        ssum = w4_swap32_add(ssum); qsum = w4_swap32_add(qsum);
+        if (l_e < 16) *reinterpret_cast<float2*>(red + red_par * (WAVES * 32) + (wave * 16 + cc_r) * 2) = make_float2(ssum, qsum);
+        st_img = it.img; st_tile = it.tile; st_cout0 = cout0; st_par = red_par; red_par ^= 1;
+    };
     auto finish = [&](int s) {
         stamp(4);
         __syncthreads();          // stage barrier: buf[nxt] complete, buf[cur] free
@@ -605,8 +747,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
         epi_prefetch();
         compute(std::true_type{});
         stamp(3);
-        epilogue();
+        if constexpr (TEPI) epilogue_t(); else epilogue();
         finish(s); ++s;
+        if constexpr (TEPI) flush_stats();      // after the stage barrier: every wave's chunk sums are in LDS (parity red_par ^ 1)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the workgroup's LDS is released
 }

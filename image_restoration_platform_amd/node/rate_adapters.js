@@ -21,7 +21,7 @@ const rawCodec = {
   const inputs = Array.from({ length: total }, () => Buffer.from(img));       // every job its own upload Buffer, built before the clock starts
   const flags = Buffer.from([1]);
   async function closedLoop(one) {
-    await Promise.all(Array.from({ length: inflight }, (_, i) => one(i)));    // warm-up
+    await Promise.all(Array.from({ length: Math.max(inflight, 16) }, (_, i) => one(i % total)));    // warm-up (two engine batches)
     const b0 = health.metrics().batches;
     const t0 = process.hrtime.bigint();
     let started = 0;
