@@ -63,6 +63,25 @@ __device__ __forceinline__ void cls_acc4(unsigned w, unsigned& s, unsigned& q) {
 __device__ __forceinline__ unsigned cls_blur3(unsigned a, unsigned b, unsigned c) {
     return ((12u * (a + c) + 20u * b + 22u) * DIV44_M) >> 19;
 }
+// The same blur with the three taps in bytes 0..2 of one word: ONE v_dot4_u32_u8 gives the numerator (byte 3 has weight 0),
+// one 24-bit multiply puts floor(n / 44) into the product's TOP BYTE: n * 381301 < 2^32 and floor(n / 44) == (n * 381301) >> 24
+// for every n <= 12 * 510 + 20 * 255 + 22 = 11242 (381301 * 44 = 2^24 + 28; tests/test_host_logic.py checks every n), so four
+// quotients pack with two byte permutes and an OR -- no shifts, no per-byte extracts.
+constexpr unsigned BLUR_W = 0x000c140cu;         // weights 12, 20, 12, 0
+constexpr unsigned DIV44_TOP = 381301u;
+__device__ __forceinline__ unsigned cls_blur_top(unsigned window) {
+    return __umul24(__builtin_amdgcn_udot4(window, BLUR_W, 22u, false), DIV44_TOP);
+}
+__device__ __forceinline__ unsigned cls_pack_top(unsigned p0, unsigned p1, unsigned p2, unsigned p3) {     // bytes 3 of p0..p3
+    return __builtin_amdgcn_perm(p1, p0, 0x0c0c0703u) | __builtin_amdgcn_perm(p3, p2, 0x07030c0cu);
+}
+// windows (x-1, x, x+1, .) of the four pixels of w1; w0 / w2 are the words to its left / right
+__device__ __forceinline__ void cls_windows(unsigned w0, unsigned w1, unsigned w2, unsigned (&win)[4]) {
+    win[0] = __builtin_amdgcn_alignbyte(w1, w0, 3);
+    win[1] = w1;
+    win[2] = __builtin_amdgcn_alignbyte(w2, w1, 1);
+    win[3] = __builtin_amdgcn_alignbyte(w2, w1, 2);
+}
 
 // One workgroup walks a strided set of 16 x 256 tiles of ONE image (blockIdx.y).  Everything between HBM and the 12 + 2
 // integer accumulators is word-wide: a thread owns a four-pixel group (three dwords of RGB bytes in, four packed u8 words
@@ -121,24 +140,31 @@ __global__ __launch_bounds__(256) void classifier_scan_kernel(const uint8_t* __r
     // Groups that straddle the image's left / right edge (replicate padding) are gathered bytewise into the same form.
     constexpr int A_ITERS = (PL_ROWS * PL_WORDS + 255) / 256;
     unsigned pre[A_ITERS][3];
+    // a thread's groups sit at the same (row, word) of every tile: decoded once (the division by the plane width and the clamps
+    // of a from-scratch decode were ~40 vector instructions per group and tile: 200 of a tile's ~1 800)
+    int a_py[A_ITERS], a_xo[A_ITERS];
+#pragma unroll
+    for (int k = 0; k < A_ITERS; ++k) {
+        const int i = min(tid + k * 256, PL_ROWS * PL_WORDS - 1);
+        a_py[k] = i / PL_WORDS - 1;                              // tile row -1 .. 16
+        a_xo[k] = 4 * (i - (i / PL_WORDS) * PL_WORDS - 1);       // first pixel of the group relative to the tile: -4 .. 256
+    }
     auto load_tile = [&](int tile) {
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         const int y0 = ty * CT_H, x0 = tx * CT_W;
 #pragma unroll
         for (int k = 0; k < A_ITERS; ++k) {
-            const int i = min(tid + k * 256, PL_ROWS * PL_WORDS - 1);
-            const int py = i / PL_WORDS, wq = i - py * PL_WORDS;
-            const int gy = min(max(y0 + py - 1, 0), H - 1);
-            const int xs = x0 + 4 * (wq - 1);
+            const int gy = min(max(y0 + a_py[k], 0), H - 1);
+            const int xs = x0 + a_xo[k];
             if (xs >= 0 && xs + 3 < W) {
-                const uint8_t* p = base + ((size_t)gy * W + xs) * 3;
+                const uint8_t* p = base + (unsigned)((gy * W + xs) * 3);          // (an image is < 2^31 bytes: check_shape caps H, W at 8192)
                 __builtin_memcpy(&pre[k][0], p, 4); __builtin_memcpy(&pre[k][1], p + 4, 4); __builtin_memcpy(&pre[k][2], p + 8, 4);
             } else {
                 unsigned char t[12];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int gx = min(max(xs + j, 0), W - 1);
-                    const uint8_t* p = base + ((size_t)gy * W + gx) * 3;
+                    const uint8_t* p = base + (unsigned)((gy * W + gx) * 3);
                     t[3 * j] = p[0]; t[3 * j + 1] = p[1]; t[3 * j + 2] = p[2];
                 }
                 pre[k][0] = cls_pack4(t[0], t[1], t[2], t[3]); pre[k][1] = cls_pack4(t[4], t[5], t[6], t[7]); pre[k][2] = cls_pack4(t[8], t[9], t[10], t[11]);
@@ -158,15 +184,16 @@ __global__ __launch_bounds__(256) void classifier_scan_kernel(const uint8_t* __r
             if (i < PL_ROWS * PL_WORDS) {
                 const int py = i / PL_WORDS, wq = i - py * PL_WORDS;
                 const unsigned d0 = pre[k][0], d1 = pre[k][1], d2 = pre[k][2];          // r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3
-                const unsigned r[4] = {cls_byte(d0, 0), cls_byte(d0, 3), cls_byte(d1, 2), cls_byte(d2, 1)};
-                const unsigned gg[4] = {cls_byte(d0, 1), cls_byte(d1, 0), cls_byte(d1, 3), cls_byte(d2, 2)};
-                const unsigned b[4] = {cls_byte(d0, 2), cls_byte(d1, 1), cls_byte(d2, 0), cls_byte(d2, 3)};
+                // the three planes by byte permutes (two per plane) instead of twelve extracts and nine packs
+                const unsigned rw = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c060300u), 0x05020100u);
+                const unsigned gw = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c070401u), 0x06020100u);
+                const unsigned bw = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x0c0c0502u), 0x07040100u);
                 unsigned yv[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) yv[j] = grey_of(r[j], gg[j], b[j]);
-                L.pl[0][py][wq] = cls_pack4(r[0], r[1], r[2], r[3]);
-                L.pl[1][py][wq] = cls_pack4(gg[0], gg[1], gg[2], gg[3]);
-                L.pl[2][py][wq] = cls_pack4(b[0], b[1], b[2], b[3]);
+                for (int j = 0; j < 4; ++j) yv[j] = grey_of(cls_byte(rw, j), cls_byte(gw, j), cls_byte(bw, j));
+                L.pl[0][py][wq] = rw;
+                L.pl[1][py][wq] = gw;
+                L.pl[2][py][wq] = bw;
                 L.pl[3][py][wq] = cls_pack4(yv[0], yv[1], yv[2], yv[3]);
             }
         }
@@ -181,10 +208,9 @@ __global__ __launch_bounds__(256) void classifier_scan_kernel(const uint8_t* __r
             if (k == 4 && rb >= 2) break;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const unsigned w0 = L.pl[c][py][g], w1 = L.pl[c][py][g + 1], w2 = L.pl[c][py][g + 2];
-                const unsigned lw = (w1 << 8) | (w0 >> 24), rw = (w1 >> 8) | (w2 << 24);      // pixels x-1 .. x+2, x+1 .. x+4
-                L.hb[c][py][g] = cls_pack4(cls_blur3(cls_byte(lw, 0), cls_byte(w1, 0), cls_byte(rw, 0)), cls_blur3(cls_byte(lw, 1), cls_byte(w1, 1), cls_byte(rw, 1)),
-                                           cls_blur3(cls_byte(lw, 2), cls_byte(w1, 2), cls_byte(rw, 2)), cls_blur3(cls_byte(lw, 3), cls_byte(w1, 3), cls_byte(rw, 3)));
+                unsigned win[4];
+                cls_windows(L.pl[c][py][g], L.pl[c][py][g + 1], L.pl[c][py][g + 2], win);
+                L.hb[c][py][g] = cls_pack_top(cls_blur_top(win[0]), cls_blur_top(win[1]), cls_blur_top(win[2]), cls_blur_top(win[3]));
             }
         }
         __syncthreads();
@@ -200,10 +226,11 @@ __global__ __launch_bounds__(256) void classifier_scan_kernel(const uint8_t* __r
             // sliding window over plane rows: h3[row][j] = grey(x-1) + grey(x) + grey(x+1) of that row
             unsigned h3[3][4], cw[3];
             auto row_sums = [&](int py, unsigned (&h)[4], unsigned& cword) {
-                const unsigned w0 = L.pl[3][py][g], w1 = L.pl[3][py][g + 1], w2 = L.pl[3][py][g + 2];
-                const unsigned lw = (w1 << 8) | (w0 >> 24), rw = (w1 >> 8) | (w2 << 24);
+                const unsigned w1 = L.pl[3][py][g + 1];
+                unsigned win[4];
+                cls_windows(L.pl[3][py][g], w1, L.pl[3][py][g + 2], win);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) h[j] = cls_byte(lw, j) + cls_byte(w1, j) + cls_byte(rw, j);
+                for (int j = 0; j < 4; ++j) h[j] = __builtin_amdgcn_udot4(win[j], 0x00010101u, 0u, false);     // grey(x-1) + grey(x) + grey(x+1)
                 cword = w1;
             };
             row_sums(rb * 4, h3[0], cw[0]);
@@ -226,9 +253,12 @@ __global__ __launch_bounds__(256) void classifier_scan_kernel(const uint8_t* __r
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
                     cls_acc4(L.pl[ch][hy][g + 1] & m, s_c[ch], q_c[ch]);
+                    // vertical pass: the three rows' bytes of a pixel gathered into one window word by two byte permutes
                     const unsigned ua = L.hb[ch][hy - 1][g], ub = L.hb[ch][hy][g], uc = L.hb[ch][hy + 1][g];
-                    const unsigned bw = cls_pack4(cls_blur3(cls_byte(ua, 0), cls_byte(ub, 0), cls_byte(uc, 0)), cls_blur3(cls_byte(ua, 1), cls_byte(ub, 1), cls_byte(uc, 1)),
-                                                  cls_blur3(cls_byte(ua, 2), cls_byte(ub, 2), cls_byte(uc, 2)), cls_blur3(cls_byte(ua, 3), cls_byte(ub, 3), cls_byte(uc, 3)));
+                    const unsigned bw = cls_pack_top(cls_blur_top(__builtin_amdgcn_perm(uc, __builtin_amdgcn_perm(ub, ua, 0x0c0c0400u), 0x0c040100u)),
+                                                     cls_blur_top(__builtin_amdgcn_perm(uc, __builtin_amdgcn_perm(ub, ua, 0x0c0c0501u), 0x0c050100u)),
+                                                     cls_blur_top(__builtin_amdgcn_perm(uc, __builtin_amdgcn_perm(ub, ua, 0x0c0c0602u), 0x0c060100u)),
+                                                     cls_blur_top(__builtin_amdgcn_perm(uc, __builtin_amdgcn_perm(ub, ua, 0x0c0c0703u), 0x0c070100u)));
                     cls_acc4(bw & m, s_b, q_b);
                 }
             }
@@ -286,9 +316,19 @@ __global__ __launch_bounds__(256) void classifier_scan_kernel(const uint8_t* __r
         __shared__ unsigned long long fin[CLS_NSUMS][16];
         const int k = tid >> 4, rl = tid & 15;
         if (k < CLS_NSUMS) {
+            // a launch has at most CLS_MAX_WG = 768 workgroups per image: <= 48 rows per lane, requested eight at a time (one
+            // round trip per eight rows instead of one per row: the accumulate made the loads of the rolled loop serial)
             unsigned long long v = 0;
-            for (unsigned b = rl; b < gridDim.x; b += 16)
-                v += __hip_atomic_load(&parts[((size_t)img * gridDim.x + b) * CLS_NSUMS + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (unsigned b0 = rl; b0 < gridDim.x; b0 += 128) {
+                unsigned long long t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const unsigned b = b0 + 16 * u;
+                    t[u] = b < gridDim.x ? __hip_atomic_load(&parts[((size_t)img * gridDim.x + b) * CLS_NSUMS + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v += t[u];
+            }
             fin[k][rl] = v;
         }
         __syncthreads();

@@ -135,3 +135,49 @@ def allgather_parts(buf, offset, local, total):
         buf[:total].copy_(full)
     else:
         dist.all_gather_into_tensor(buf[:total], buf[offset:offset + local])
+
+
+def exchange_step(send_up, send_down, recv_up, recv_down, halo_bytes, stats_buf, offset, local, total, rank=None, world=None):
+    """ONE grouped launch per op (cfg 4): the op's halo rows (to / from the two neighbouring strips) AND its slice of the
+    GroupNorm partials (to / from every other rank) as point-to-point operations of a single batch_isend_irecv group
+    (= one ncclGroupStart / End under RCCL): per-op exchange latency is paid once, not once for the halo rows and once for
+    an all-gather.  The partials travel rank-to-rank on the direct xGMI links (a full mesh: every pair has its own link), in
+    place: rank r's slice lands at r * local of every rank's `stats_buf`, exactly what allgather_parts produced, so the
+    finalize still adds the untiled run's partials in the untiled run's order (bit-identical results).
+    halo_bytes == 0: no halo rows for this op; local == 0: no statistics.  Returns the number of exchange launches (0 or 1)."""
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    if world == 1 or (halo_bytes == 0 and local == 0):
+        return 0
+    ops, post = [], []
+    if halo_bytes:
+        stage = _staged(send_up)
+        su, sd = (send_up[:halo_bytes].cpu(), send_down[:halo_bytes].cpu()) if stage else (send_up[:halo_bytes], send_down[:halo_bytes])
+        ru = torch.empty(halo_bytes, dtype=torch.uint8) if stage else recv_up[:halo_bytes]
+        rd = torch.empty(halo_bytes, dtype=torch.uint8) if stage else recv_down[:halo_bytes]
+        if rank > 0:
+            ops += [dist.P2POp(dist.isend, su, rank - 1), dist.P2POp(dist.irecv, ru, rank - 1)]
+            if stage:
+                post.append((recv_up[:halo_bytes], ru))
+        if rank + 1 < world:
+            ops += [dist.P2POp(dist.isend, sd, rank + 1), dist.P2POp(dist.irecv, rd, rank + 1)]
+            if stage:
+                post.append((recv_down[:halo_bytes], rd))
+    if local:
+        assert local * world == total and offset == rank * local
+        stage = _staged(stats_buf)
+        mine = stats_buf[offset:offset + local].cpu() if stage else stats_buf[offset:offset + local]
+        for r in range(world):
+            if r == rank:
+                continue
+            dst = torch.empty(local, dtype=torch.uint8) if stage else stats_buf[r * local:(r + 1) * local]
+            ops += [dist.P2POp(dist.isend, mine, r), dist.P2POp(dist.irecv, dst, r)]
+            if stage:
+                post.append((stats_buf[r * local:(r + 1) * local], dst))
+    if not ops:
+        return 0
+    for q in dist.batch_isend_irecv(ops):
+        q.wait()
+    for dev_t, host_t in post:
+        dev_t.copy_(host_t)
+    return 1

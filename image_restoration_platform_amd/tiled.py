@@ -24,17 +24,34 @@ def split_rows(img_u8, rank, world):
     return out
 
 
-def restore_strip(sess, rows_with_halo, scores, sharding, stream=None):
-    """This rank's strip through the network.  sess: engine.StripSession (1 strip per rank); returns the strip's restored rows."""
+def restore_strip(sess, rows_with_halo, scores, sharding, stream=None, grouped=True, counter=None):
+    """This rank's strip through the network.  sess: engine.StripSession (1 strip per rank); returns the strip's restored rows.
+    grouped (default): ONE exchange launch per op -- its halo rows and its slice of the GroupNorm partials in one group of
+    point-to-point operations (sharding.exchange_step); grouped=False: round 2's two launches per op (halo exchange, then an
+    all-gather), kept for A/B.  counter: a dict whose "exchanges" entry is incremented per exchange launch."""
     sess.set_input(rows_with_halo, scores, stream)
+    n = 0
     for k in range(sess.num_ops):
         info = sess.run_op(k, stream)
-        if info.halo_bytes:
+        hb, loc = int(info.halo_bytes), int(info.stats_local_bytes)
+        if grouped:
+            if hb:
+                sess.pack_halo(k, stream)
+            n += sharding.exchange_step(sess.send_up, sess.send_down, sess.recv_up, sess.recv_down, hb,
+                                        sess.stats, int(info.stats_offset_bytes), loc, int(info.stats_total_bytes))
+            if hb:
+                sess.unpack_halo(k, stream)
+            continue
+        if hb:
             sess.pack_halo(k, stream)
-            sharding.exchange_halos(sess.send_up, sess.send_down, sess.recv_up, sess.recv_down, int(info.halo_bytes))
+            sharding.exchange_halos(sess.send_up, sess.send_down, sess.recv_up, sess.recv_down, hb)
             sess.unpack_halo(k, stream)
-        if info.stats_local_bytes:
-            sharding.allgather_parts(sess.stats, int(info.stats_offset_bytes), int(info.stats_local_bytes), int(info.stats_total_bytes))
+            n += 1
+        if loc:
+            sharding.allgather_parts(sess.stats, int(info.stats_offset_bytes), loc, int(info.stats_total_bytes))
+            n += 1
+    if counter is not None:
+        counter["exchanges"] = counter.get("exchanges", 0) + n
     return sess.get_output(stream)
 
 

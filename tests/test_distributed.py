@@ -162,6 +162,81 @@ def _strip_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _strip_worker_grouped(rank, world, port, q):
+    """The same toy strip network with ONE grouped exchange per layer (sharding.exchange_step): the raw layer output's boundary
+    rows and the layer's partial statistic travel in one group of point-to-point operations; the consumer normalises the halo
+    rows it received with the same global statistic as its own rows (what the engine does: GroupNorm is applied while staging)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        H, W, hr = 8 * world, 6, 8
+        rng = np.random.default_rng(3)
+        img = rng.integers(0, 50, (H, W)).astype(np.int64)
+
+        def layer(x_with_halo):
+            p = np.pad(x_with_halo, ((0, 0), (1, 1)))
+            return sum(p[dy:dy + x_with_halo.shape[0] - 2, dx:dx + W] for dy in range(3) for dx in range(3))
+
+        def whole(x):
+            for _ in range(3):
+                x = layer(np.pad(x, ((1, 1), (0, 0))))
+                x = x - int(x.sum()) // x.size
+            return x
+
+        x = img[rank * hr:(rank + 1) * hr].copy()
+        row_bytes = W * 8
+        su, sd, ru, rd = (torch.zeros(row_bytes, dtype=torch.uint8) for _ in range(4))
+        parts = torch.zeros(world * 8, dtype=torch.uint8)
+        steps = 0
+
+        def xchg(x, with_stats):
+            nonlocal steps
+            su.copy_(torch.from_numpy(x[0].copy().view(np.uint8)))
+            sd.copy_(torch.from_numpy(x[-1].copy().view(np.uint8)))
+            ru.zero_(); rd.zero_()
+            if with_stats:
+                parts[rank * 8:(rank + 1) * 8] = torch.from_numpy(np.array([x.sum()], np.int64).view(np.uint8))
+            steps += sharding.exchange_step(su, sd, ru, rd, row_bytes, parts, rank * 8, 8 if with_stats else 0, world * 8)
+            up = ru.numpy().view(np.int64).copy() if rank > 0 else None
+            dn = rd.numpy().view(np.int64).copy() if rank + 1 < world else None
+            return up, dn
+
+        up, dn = xchg(x, False)                     # the input image's boundary rows
+        for i in range(3):
+            zero = np.zeros(W, np.int64)
+            x = layer(np.concatenate([(up if up is not None else zero)[None], x, (dn if dn is not None else zero)[None]], axis=0))
+            if i < 2:
+                up, dn = xchg(x, True)              # ONE step: halo rows of the raw output + its statistic
+            else:
+                parts[rank * 8:(rank + 1) * 8] = torch.from_numpy(np.array([x.sum()], np.int64).view(np.uint8))
+                steps += sharding.exchange_step(su, sd, ru, rd, 0, parts, rank * 8, 8, world * 8)     # statistics only
+            mean = int(parts.numpy().view(np.int64).sum()) // (H * W)
+            x = x - mean
+            if i < 2:
+                up = up - mean if up is not None else None
+                dn = dn - mean if dn is not None else None
+        q.put((rank, x, whole(img)[rank * hr:(rank + 1) * hr], steps))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cfg4_grouped_exchange_step_reproduces_the_whole_image():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_strip_worker_grouped, args=(r, 3, port, q)) for r in range(3)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(3)]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, got, want, steps in res:
+        assert (got == want).all(), rank
+        assert steps == 4, steps          # input rows + one grouped step per layer (the ungrouped form needs 3 + 3)
+
+
 def test_cfg4_strip_exchange_functions_reproduce_the_whole_image():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")

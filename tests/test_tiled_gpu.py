@@ -59,6 +59,7 @@ def _rank(rank, world, port, h, w, q):
     from image_restoration_platform_amd.engine import Engine
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+      try:
         torch.cuda.set_device(0)
         eng = Engine(device_index=0, max_batch=1)
         img = torch.from_numpy(synth.batch(1, h, w, start=77)[0]).cuda()
@@ -66,16 +67,23 @@ def _rank(rank, world, port, h, w, q):
         scores, _ = eng.classify_tensor(img[None], jp)           # "the rank that took the job classified it"; here every rank can
         sess = eng.open_strips(h, w, world, rank, 1)
         rows = tiled.split_rows(img, rank, world).contiguous()
-        out = tiled.restore_strip(sess, rows, scores[0], sharding)
+        cnt, cnt2 = {}, {}
+        out = tiled.restore_strip(sess, rows, scores[0], sharding, counter=cnt)            # one grouped exchange launch per op
         torch.cuda.synchronize()
+        out2 = tiled.restore_strip(sess, rows, scores[0], sharding, grouped=False, counter=cnt2)   # round 2's halo exchange + all-gather
+        torch.cuda.synchronize()
+        assert torch.equal(out, out2)
         ok = None
         if rank == 0:
             whole = eng.restore_tensor(img[None], scores=scores)[0]
             torch.cuda.synchronize()
             ok = whole.cpu().numpy()
-        q.put((rank, out.cpu().numpy(), ok))
+        q.put((rank, out.cpu().numpy(), ok, cnt["exchanges"], cnt2["exchanges"]))
         sess.close()
         eng.close()
+      except BaseException as e:       # the parent must hear about a failure here: a silent child would only show as a queue timeout
+        q.put((rank, repr(e), None, -1, -1))
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -90,10 +98,17 @@ def test_two_ranks_exchange_halos_and_partials_bit_identical():
     ps = [ctx.Process(target=_rank, args=(r, 2, port, h, w, q)) for r in range(2)]
     for p in ps:
         p.start()
-    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda t: t[0])
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
     for p in ps:
         p.join(120)
-        assert p.exitcode == 0
+    assert all(not isinstance(r[1], str) for r in res), [r[1] for r in res if isinstance(r[1], str)]
+    assert all(p.exitcode == 0 for p in ps)
+    # exchange launches per image and rank: one grouped launch per op (its halo rows + its slice of the GroupNorm partials) against
+    # round 2's halo exchange + all-gather per op
+    grouped, ungrouped = res[0][3], res[0][4]
+    assert res[1][3] == grouped and res[1][4] == ungrouped
+    assert grouped <= 42 and ungrouped > grouped + 30, (grouped, ungrouped)
+    print("cfg 4 exchange launches per image: grouped %d, halo + all-gather %d" % (grouped, ungrouped))
     whole = res[0][2]
     got = np.concatenate([res[0][1], res[1][1]], axis=0)
     assert got.shape == whole.shape == (h, w, 3)
