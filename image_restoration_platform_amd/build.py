@@ -29,7 +29,8 @@ SOURCES = [
     ("conv_f8.hip", []),
     ("conv_pc.hip", (["-DC3_ABL=" + os.environ["C3_ABL"]] if os.environ.get("C3_ABL") else []) +
      (["-DC3_PRIO=" + os.environ["C3_PRIO"]] if os.environ.get("C3_PRIO") else []) +
-     (["-DC3_RES_PRE=" + os.environ["C3_RES_PRE"]] if os.environ.get("C3_RES_PRE") else [])),
+     (["-DC3_RES_PRE=" + os.environ["C3_RES_PRE"]] if os.environ.get("C3_RES_PRE") else []) +
+     (["-DC3_TEPI=" + os.environ["C3_TEPI"]] if os.environ.get("C3_TEPI") else [])),
     ("gn.hip", []),
     ("fusion.hip", []),
     ("preprocess.hip", []),

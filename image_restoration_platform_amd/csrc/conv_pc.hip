@@ -40,6 +40,10 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #ifndef C3_PRIO
 #define C3_PRIO 1     // measured: priority 1 for the producer waves +0.5 % (911 -> 916 img/s); 3 the same
 #endif
+#ifndef C3_TEPI
+#define C3_TEPI 0    // 1: C = 32 line-coalesced epilogue through a wave-private LDS transpose patch (build-time A/B).  Measured NEUTRAL (same box, twice
+                     // each: RB2 314.3 / 318.8 vs 314.8 / 315.3 us, RB1 265.0 / 271.0 vs 266.6 / 267.5): the addresser's busy cycles fall, the kernel's time does not
+#endif
 #ifndef C3_ABL
 #define C3_ABL 0     // timing ablations (results wrong by design): 1 no transform, 2 no epilogue, 4 no MFMA loop, 8 no input loads, 16 no output stores, 32 no statistics, 64 no residual loads
 #endif
@@ -65,7 +69,8 @@ template <int C> struct PcCfg {
     static constexpr int COEF_IMGS = C == 32 ? 64 : C == 64 ? 8 : 2;            // images whose (A, B) the LDS table holds
     static constexpr int COEF_OFF = RED_OFF + 2 * RED_HALF * 4;
     static constexpr int HEAD_OFF = COEF_OFF + COEF_IMGS * C * 2 * 4;           // head: [8 waves][in | out][2 rows][96 B]
-    static constexpr int LDS = HEAD_OFF + (C == 32 ? 8 * 2 * 2 * 96 : 0);
+    static constexpr int PATCH_OFF = HEAD_OFF + (C == 32 ? 8 * 2 * 2 * 96 : 0);   // C = 32: [8 waves][32 pixels x 64 B] transpose patches of the line-coalesced epilogue
+    static constexpr int LDS = PATCH_OFF + (C == 32 ? 8 * 2048 : 0);
     static_assert(LDS <= 160 * 1024, "LDS");
     static_assert(!STREAM || W_STAGE_CHUNKS == 9 * C3_PROD, "a producer thread streams 9 weight chunks per stage");
 };
@@ -348,6 +353,17 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
     constexpr int RES_PRE = C3_RES_PRE < 2 * NTL ? C3_RES_PRE : 2 * NTL;    // residual groups requested before the MFMAs; the rest after the k-loop
     unsigned eoffs[2];
     bool einb[2];
+    // C = 32 line-coalesced epilogue (TEPI, off by default -- see C3_TEPI): the accumulator layout (lane = pixel) makes every lane
+    // of a quad address a different pixel, and the texture addresser coalesces only within a quad: a 16-B-per-lane store of 32
+    // pixels x 32 B costs ~66 of its cycles, a residual load of that shape ~115, against 16 for quad-contiguous addresses (PMC: TA
+    // busy 72 % of the C = 32 residual kernel, profiles/r03_experiments.md).  With TEPI a wave transposes a pixel row through its
+    // own 2-KB LDS patch (XOR-swizzled: conflict-free both ways) so that four consecutive lanes hold one pixel's 64 B and every
+    // global instruction of the epilogue is 1 KB contiguous.  Correct (same tests), and neutral in time: the addresser was busy,
+    // not limiting.
+    constexpr bool TEPI = C3_TEPI && C == 32 && !HEAD;
+    unsigned toffs[2];            // byte offset of (read-back pixel lane >> 2 of row m, chunk lane & 3) in the output image
+    bool trow[2];
+    int tcol = 0;
     unsigned hin[2] = {0u, 0u};           // head: this lane's dword of the two image rows
     size_t hoff[2] = {0, 0};
     bool hok[2] = {false, false};
@@ -367,7 +383,28 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
                 einb[m] = colok && oy < a.Hout;
                 eoffs[m] = ((unsigned)((min(oy, a.Hout - 1) * a.Wout + oxc) * C + it.nb * NT) << 1) + (unsigned)(h * 16);
             }
-            if constexpr (RESID && (C3_ABL & 64)) {
+            if constexpr (TEPI) {
+                tcol = it.tx * C3_TW + (lane >> 2);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int oy = oyb + m;
+                    trow[m] = oy < a.Hout;
+                    toffs[m] = ((unsigned)((min(oy, a.Hout - 1) * a.Wout + tcol) * C + 8 * (lane & 3)) << 1);
+                }
+            }
+            if constexpr (RESID && TEPI && !(C3_ABL & 64)) {
+                // the residual rows in the read-back layout: two 1-KB requests per row, before the MFMAs
+                char* rbase = const_cast<char*>(reinterpret_cast<const char*>(a.resid)) + (size_t)it.img * a.Hout * a.Wout * (2 * C);
+                const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(rbase, 0, a.Hout * a.Wout * (2 * C), 0x00020000);
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const bool ok = trow[m] && tcol + 16 * k < a.Wout;
+                        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ok ? toffs[m] + (unsigned)(16 * k * 2 * C) : 0xffffffffu, 0, 0);
+                        erv[k][m] = make_uint4(v.x, v.y, v.z, v.w);
+                    }
+            } else if constexpr (RESID && (C3_ABL & 64)) {
 #pragma unroll
                 for (int g = 0; g < 2 * NTL; ++g)
 #pragma unroll
@@ -483,6 +520,66 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int j = 0; j < NTL; ++j) asm volatile("" :: "v"(acc[m][j]));       // every accumulator stays live: no MFMA may be optimised away
+        } else if constexpr (TEPI) {
+            char* obase = reinterpret_cast<char*>(a.out) + (size_t)it.img * a.Hout * a.Wout * (2 * C);
+            const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.Hout * a.Wout * (2 * C), 0x00020000);
+            const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+            float* redw = red_base + red_par * K::RED_HALF;
+            unsigned char* patch = smem + K::PATCH_OFF + wave * 2048;
+            const int wsw = (r >> 1) & 3;                                  // writer: pixel r, chunks 2 pp + h
+            const int pq = lane >> 2, cq = lane & 3;                       // reader: pixel pq + 16 k, chunk cq (couts 8 cq .. 8 cq + 7)
+            float sA = 0.f, qA = 0.f, sB = 0.f, qB = 0.f;                  // groups 2 cq (couts 0..3 of the chunk) and 2 cq + 1
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const f32x16_t& c = acc[m][0];
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    const u32x4_t wv = {c3_pack(c[8 * pp + 0], c[8 * pp + 1]), c3_pack(c[8 * pp + 2], c[8 * pp + 3]),
+                                        c3_pack(c[8 * pp + 4], c[8 * pp + 5]), c3_pack(c[8 * pp + 6], c[8 * pp + 7])};
+                    *reinterpret_cast<u32x4_t*>(patch + r * 64 + (((2 * pp + h) ^ wsw) << 4)) = wv;
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int p = pq + 16 * k;
+                    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(patch + p * 64 + ((cq ^ ((p >> 1) & 3)) << 4));
+                    unsigned w[4] = {v.x, v.y, v.z, v.w};
+                    if constexpr (RESID) {
+                        const uint4 rr = erv[k][m];
+                        const unsigned rw[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) w[d] = c3_pack(c3_lo(w[d]) + c3_lo(rw[d]), c3_hi(w[d]) + c3_hi(rw[d]));
+                    }
+                    const bool ok = trow[m] && tcol + 16 * k < a.Wout;
+                    const float mf = ok ? 1.f : 0.f;
+                    float ts0 = 0.f, tq0 = 0.f, ts1 = 0.f, tq1 = 0.f;
+                    if constexpr (!(C3_ABL & 32))
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const bf16x2_t bv = __builtin_bit_cast(bf16x2_t, w[d]);
+                        if (d < 2) { ts0 = __builtin_amdgcn_fdot2_f32_bf16(bv, ones, ts0, false); tq0 = __builtin_amdgcn_fdot2_f32_bf16(bv, bv, tq0, false); }
+                        else { ts1 = __builtin_amdgcn_fdot2_f32_bf16(bv, ones, ts1, false); tq1 = __builtin_amdgcn_fdot2_f32_bf16(bv, bv, tq1, false); }
+                    }
+                    sA = __builtin_fmaf(ts0, mf, sA); qA = __builtin_fmaf(tq0, mf, qA);
+                    sB = __builtin_fmaf(ts1, mf, sB); qB = __builtin_fmaf(tq1, mf, qB);
+                    const u32x4_t o4 = {w[0], w[1], w[2], w[3]};
+                    if constexpr (C3_ABL & 16) asm volatile("" :: "v"(o4));
+                    else __builtin_amdgcn_raw_buffer_store_b128(o4, orsrc, ok ? toffs[m] + (unsigned)(16 * k * 2 * C) : 0xffffffffu, 0, 0);
+                }
+            }
+            if constexpr (!(C3_ABL & 32)) {
+                // the sixteen lanes that share a chunk sit 4 apart: two rotations within the row of 16, then the rows
+                float t4[4] = {sA, qA, sB, qB};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t4[k] = c3_ror_add<4>(t4[k]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t4[k] = c3_ror_add<8>(t4[k]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t4[k] = c3_swap16_add(t4[k]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { float x = t4[k], y = t4[k]; asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y)); t4[k] = x + y; }
+                if (lane < 4) *reinterpret_cast<float4*>(redw + (wave * NCC + lane) * 4) = make_float4(t4[0], t4[1], t4[2], t4[3]);
+            }
+            st_img = it.img; st_tile = it.tile; st_nb = it.nb; st_par = red_par; red_par ^= 1;
         } else {
             char* obase = reinterpret_cast<char*>(a.out) + (size_t)it.img * a.Hout * a.Wout * (2 * C);
             const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.Hout * a.Wout * (2 * C), 0x00020000);

@@ -1,16 +1,18 @@
 // conv_stem.hip -- RestoreNet-v0's first layer (u8 RGB -> 32 channels, 3x3) as a kernel of its own, gfx950.
 //
-// K = 3 x 3 x 3 = 27: one 16x32-pixel tile of u8 input is 1.8 KB and the whole layer is two MFMAs per 32 pixels, so the
+// K = 3 x 3 x 3 = 27: one 16x32-pixel tile of u8 input is 1.8 KB and the whole layer is three MFMAs per 32 pixels, so the
 // kernel is its output stream (64 B per pixel: 537 MB per 8 x 1024^2) plus a small epilogue.  The v1 template (conv_mfma.hip)
 // padded the 3 channels to 8 and ran the generic 9-tap schedule: 177 us; this kernel 150 us (181 before the next tile's bytes were
 // requested ahead).  An ideal fill of the output's size takes 84 us.
 //
 //   * a workgroup (512 threads) stages a tile's 18 x 34 x 3 bytes as bf16 (u8 -> bf16 is exact) in LDS, zero outside the image;
 //     the bytes of the NEXT tile are requested before this tile's arithmetic (four per thread, in registers)
-//   * a wave owns two pixel rows: per row two K = 16 steps of `v_mfma_f32_32x32x16_bf16`, couts on rows (permuted like every
-//     other slab: a lane owns 8 contiguous couts), k = ky*9 + kx*3 + c, k >= 27 reads a zero
-//   * the B fragment of lane (pixel r, half h), step ks is k = 16 ks + 8 h .. + 8: elements of up to two tile rows, gathered
-//     with 16-bit LDS reads from per-lane offsets computed once per kernel
+//   * the LDS tile holds a pixel as FOUR bf16 (R, G, B, 0): 8 bytes.  K is laid out as k = 16 ky + 4 kx + c with kx in 0..3 and
+//     c in 0..3 (kx = 3 and c = 3 carry zero weights): k-step ky of `v_mfma_f32_32x32x16_bf16` is one tile row, and the B
+//     fragment of lane (pixel r, half h) -- k = 16 ky + 8 h .. + 8 = pixels r + 2h, r + 2h + 1 -- is 16 CONTIGUOUS bytes: one
+//     `ds_read2_b64` per fragment, conflict-free.  (Round 2 packed K to 27 = two k-steps and gathered each fragment with eight
+//     16-bit reads from per-lane offsets: 40 % of its LDS cycles were bank conflicts, 62 vector instructions per MFMA.)
+//   * a wave owns two pixel rows: per row three MFMAs, couts on rows (permuted like every other slab: a lane owns 8 contiguous couts)
 //   * epilogue as conv_pc's: accumulators start at the bias, bf16 stores straight from the accumulators, GroupNorm partial
 //     statistics (8 groups of 4 channels) of the stored values per tile
 #include "conv_mfma.hpp"
@@ -28,9 +30,9 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int ST_THREADS = 512, ST_TH = 16, ST_TW = 32, ST_IH = ST_TH + 2, ST_IW = ST_TW + 2;
-constexpr int ST_RB = ST_IW * 3;            // bytes (= elements) of a tile row: 102
-constexpr int ST_ROW = 104;                 // LDS row pitch in bf16 elements
-constexpr int ST_ZERO = ST_IH * ST_ROW;     // an element that is always zero (k >= 27)
+constexpr int ST_RB = ST_IW * 3;            // bytes of a tile row in the image: 102
+constexpr int ST_PW = ST_IW + 2;            // pixels per LDS row: the fragment of pixel r = 31, h = 1 reaches pixel 34 (zero weight) -- kept finite (zero)
+constexpr int ST_ROW = ST_PW * 4;           // LDS row pitch in bf16 elements (4 per pixel)
 constexpr int ST_ITERS = (ST_IH * ST_RB + ST_THREADS - 1) / ST_THREADS;     // 4 bytes per thread and tile
 
 __device__ __forceinline__ unsigned st_pack(float a, float b) {
@@ -50,28 +52,25 @@ __device__ __forceinline__ float st_swap16_add(float v) {
 // two workgroups per CU (119 registers): they overlap one another's staging, arithmetic and stores; three would need <= 80
 // registers (36 spilled: 289 us against 150)
 __global__ __launch_bounds__(ST_THREADS) void conv_stem_kernel(ConvArgs a) {
-    __shared__ unsigned short tile[2][ST_IH * ST_ROW + ST_ROW + 8];       // + zero elements at ST_ZERO and ST_ZERO + ST_ROW (k >= 27, rows m = 0 / 1)
+    __shared__ __attribute__((aligned(16))) unsigned short tile[2][ST_IH * ST_ROW];
     __shared__ float red[2][8][8][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
 
-    // A fragments (weights): [ks][h][32 permuted rows][8] bf16, engine.cpp::make_conv (d_wstem)
+    // A fragments (weights): [ky][h][32 permuted rows][8] bf16, engine.cpp::make_conv (d_wstem)
     const u32x4_t* wf = reinterpret_cast<const u32x4_t*>(a.w);
     const bf16x8_t w0 = __builtin_bit_cast(bf16x8_t, wf[(0 * 2 + h) * 32 + r]);
     const bf16x8_t w1 = __builtin_bit_cast(bf16x8_t, wf[(1 * 2 + h) * 32 + r]);
+    const bf16x8_t w2 = __builtin_bit_cast(bf16x8_t, wf[(2 * 2 + h) * 32 + r]);
     // accumulator i of lane-half h is cout 16 (i >> 3) + 8 h + (i & 7) (permuted slab rows)
     f32x16_t bias_acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) bias_acc[i] = a.bias[16 * (i >> 3) + 8 * h + (i & 7)];
-    // element offsets of this lane's B fragments relative to (first tile row of the output row) * ST_ROW + 3 r
-    int koff[2][8];                                  // element index within a tile for this wave's row m = 0 (m = 1: + ST_ROW)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = 16 * ks + 8 * h + e, ky = k / 9, rem = k - ky * 9;
-            koff[ks][e] = k < 27 ? (2 * wave + ky) * ST_ROW + 3 * r + rem : ST_ZERO;
-        }
-    if (tid < ST_ROW + 8) { tile[0][ST_ZERO + tid] = 0; tile[1][ST_ZERO + tid] = 0; }
+    // this lane's B fragments: 8 elements from pixel r + 2h of tile row 2 wave + m + ky
+    const int foff = (2 * wave * ST_PW + r + 2 * h) * 4;      // element index for m = 0, ky = 0
+    // the fourth element of every pixel and the two pad pixels of every row are never staged: zero them once (a zero weight does
+    // not neutralise a NaN bit pattern left in LDS)
+    for (int i = tid; i < 2 * ST_IH * ST_ROW / 2; i += ST_THREADS) reinterpret_cast<unsigned*>(&tile[0][0])[i] = 0u;
+    __syncthreads();
     // this thread's bytes of a tile: element i = tid + 512 it -> (row py, byte b of the row): the same for every tile
     int spy[ST_ITERS], sb[ST_ITERS], spx[ST_ITERS], srel[ST_ITERS];
 #pragma unroll
@@ -106,7 +105,7 @@ __global__ __launch_bounds__(ST_THREADS) void conv_stem_kernel(ConvArgs a) {
         unsigned short* tl = tile[par];
 #pragma unroll
         for (int it = 0; it < ST_ITERS; ++it)
-            if (spy[it] < ST_IH) tl[spy[it] * ST_ROW + sb[it]] = (unsigned short)(__builtin_bit_cast(unsigned, (float)pv[it]) >> 16);      // u8 -> bf16: exact
+            if (spy[it] < ST_IH) tl[spy[it] * ST_ROW + spx[it] * 4 + (sb[it] - spx[it] * 3)] = (unsigned short)(__builtin_bit_cast(unsigned, (float)pv[it]) >> 16);      // u8 -> bf16: exact
         if (item + (int)gridDim.x < total) request(item + gridDim.x);      // in flight across this tile's arithmetic and stores
         __syncthreads();                               // tile[par] is staged (its previous readers passed the barrier of the tile before last)
         // ---- per pixel row: two MFMAs, then stores + GroupNorm partials (groups of 4 channels: a lane's 8 contiguous couts are two groups) ----
@@ -115,16 +114,16 @@ __global__ __launch_bounds__(ST_THREADS) void conv_stem_kernel(ConvArgs a) {
         float gs[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gq[2][2] = {{0.f, 0.f}, {0.f, 0.f}};      // [pp][half of the 8 couts]
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            u32x4_t f[2];
+            u32x4_t f[3];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const unsigned lo = tl[koff[ks][2 * d] + m * ST_ROW], hi = tl[koff[ks][2 * d + 1] + m * ST_ROW];
-                    f[ks][d] = lo | (hi << 16);
-                }
+            for (int ky = 0; ky < 3; ++ky) {
+                const uint2* fp = reinterpret_cast<const uint2*>(tl + foff + (m + ky) * ST_ROW);      // 8-byte aligned, 16 contiguous bytes
+                const uint2 lo = fp[0], hi = fp[1];
+                f[ky] = u32x4_t{lo.x, lo.y, hi.x, hi.y};
+            }
             f32x16_t c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, __builtin_bit_cast(bf16x8_t, f[0]), bias_acc, 0, 0, 0);     // D[cout][pixel]
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, __builtin_bit_cast(bf16x8_t, f[1]), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, __builtin_bit_cast(bf16x8_t, f[2]), c, 0, 0, 0);
             const int oy = ty * ST_TH + 2 * wave + m;
             const bool inb = ox < a.Wout && oy < a.Hout;
             const float mf = inb ? 1.f : 0.f;
@@ -186,7 +185,7 @@ __global__ __launch_bounds__(ST_THREADS) void conv_stem_kernel(ConvArgs a) {
 }  // namespace
 
 // a.in0 = u8 [nimg][in_rows][Win][3] (rows iy_lo .. iy_lo + iy_span readable, the rest zero), a.out = bf16 [nimg][Hout][Wout][32],
-// a.w = A fragments [2][2][32][8] bf16 (engine.cpp::make_conv), a.bias[32], a.stats partials [img][tile][8][2]; 16x32 tiles
+// a.w = A fragments [3][2][32][8] bf16 (engine.cpp::make_conv), a.bias[32], a.stats partials [img][tile][8][2]; 16x32 tiles
 void conv_stem_launch(const ConvArgs& a, hipStream_t stream) {
     if (a.cout != 32 || a.Hout != a.Hin || a.Wout != a.Win || !a.stats) fail(IRE_ERR_INTERNAL, "internal: conv_stem shape");
     const int items = a.tiles_x * a.tiles_y * a.nimg;

@@ -245,16 +245,16 @@ ConvW Engine::make_conv(ConvKind kind, const std::string& wname, const std::stri
         IRE_HIP(hipMemcpy(c.d_wp, arrp.data(), arrp.size() * 2, hipMemcpyHostToDevice));
     }
     if (kind == CONV_STEM && cin == 3 && cout == 32) {
-        // conv_stem.hip: lane (row rho, half h) of k-step ks holds W[perm(rho)][k = 16 ks + 8 h + e], k = ky*9 + kx*3 + c, zero from 27
-        std::vector<unsigned short> arrs(2 * 2 * 32 * 8, 0);
-        for (int ks = 0; ks < 2; ++ks)
+        // conv_stem.hip: k-step ky is one tile row; lane (row rho, half h) holds W[perm(rho)] at k = 16 ky + 8 h + e, i.e. kx = 2 h + (e >> 2),
+        // c = e & 3 -- zero for the pad positions kx = 3 and c = 3 (the LDS tile holds a pixel as four bf16: R, G, B, 0)
+        std::vector<unsigned short> arrs(3 * 2 * 32 * 8, 0);
+        for (int ky = 0; ky < 3; ++ky)
             for (int hh = 0; hh < 2; ++hh)
                 for (int rho = 0; rho < 32; ++rho)
                     for (int e = 0; e < 8; ++e) {
-                        const int k = 16 * ks + 8 * hh + e;
-                        if (k >= 27) continue;
-                        const int ky = k / 9, rem = k % 9, kx = rem / 3, ch = rem % 3;
-                        arrs[(((size_t)ks * 2 + hh) * 32 + rho) * 8 + e] = f32_to_bf16(W[((size_t)perm(rho) * cin + ch) * 9 + ky * 3 + kx]);
+                        const int kx = 2 * hh + (e >> 2), ch = e & 3;
+                        if (kx >= 3 || ch >= 3) continue;
+                        arrs[(((size_t)ky * 2 + hh) * 32 + rho) * 8 + e] = f32_to_bf16(W[((size_t)perm(rho) * cin + ch) * 9 + ky * 3 + kx]);
                     }
         c.d_wstem = (unsigned short*)dalloc(arrs.size() * 2);
         net_.allocs.push_back(c.d_wstem);

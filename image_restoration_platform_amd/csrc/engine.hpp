@@ -29,7 +29,7 @@ struct ConvW {
     unsigned short* d_w = nullptr;
     unsigned short* d_wp = nullptr;   // slabs with permuted cout rows for conv_rb.hip's direct epilogue
     unsigned short* d_w4 = nullptr;  // second arrangement for conv_w4.hip (C >= 128 ResBlock convs): 16-channel stages, 128-cout blocks
-    unsigned short* d_wstem = nullptr;  // CONV_STEM as MFMA A fragments (conv_stem.hip): [ks 2][h 2][32 permuted rows][8], k = ky*9 + kx*3 + c (27 of 32)
+    unsigned short* d_wstem = nullptr;  // CONV_STEM as MFMA A fragments (conv_stem.hip): [ky 3][h 2][32 permuted rows][8], k = 16 ky + 4 kx + c (kx = 3, c = 3: zero)
     unsigned short* d_wd = nullptr;  // CONV_DOWN by pixel phase (conv_down.hip): [nblock64][kc32][phase: 1+2+2+4 taps][tap*4 + c8][64][8]
     unsigned short* d_wu = nullptr;  // CONV_UP as a sub-pixel conv (conv_up.hip): [nblock32][kc32][parity][kk][32][8], taps pre-summed per parity
     // CONV_UP composed with the level's 1x1 `fuse` (engine.cpp::make_up_fused; conv_up.hip fused form)

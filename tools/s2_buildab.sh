@@ -6,8 +6,8 @@ for v in ${ABL_VALUES}; do
   env $ABL_VAR=$v python -m image_restoration_platform_amd.build > /dev/null 2>&1 || { echo build failed; exit 1; }
   if [ -n "$ABL_TESTS" ]; then timeout -k 10 600 python -m pytest $ABL_TESTS -x -q -m gpu > $O/bab_tests_$v.log 2>&1; tail -3 $O/bab_tests_$v.log; fi
   cd /tmp; export TMPDIR=/tmp; rm -rf $O/bab_$v
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/bab_$v -o r --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bab_$v.log 2>&1
-  cd $R; timeout -k 10 200 python bench.py --no-cpu-baseline --no-profile > $O/bab_$v.json 2>> $O/bab_err.log
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/bab_$v -o r --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-path > $O/bab_$v.log 2>&1
+  cd $R; timeout -k 10 200 python bench.py --no-cpu-baseline --no-host-path --no-profile > $O/bab_$v.json 2>> $O/bab_err.log
   python3 - <<PY
 import csv, glob, json
 f = glob.glob("$O/bab_$v/**/r_kernel_stats.csv", recursive=True)[0]
