@@ -30,7 +30,9 @@ SOURCES = [
     ("conv_pc.hip", (["-DC3_ABL=" + os.environ["C3_ABL"]] if os.environ.get("C3_ABL") else []) +
      (["-DC3_PRIO=" + os.environ["C3_PRIO"]] if os.environ.get("C3_PRIO") else []) +
      (["-DC3_RES_PRE=" + os.environ["C3_RES_PRE"]] if os.environ.get("C3_RES_PRE") else []) +
-     (["-DC3_TEPI=" + os.environ["C3_TEPI"]] if os.environ.get("C3_TEPI") else [])),
+     (["-DC3_TEPI=" + os.environ["C3_TEPI"]] if os.environ.get("C3_TEPI") else []) +
+     (["-DC3_TEPI64=" + os.environ["C3_TEPI64"]] if os.environ.get("C3_TEPI64") else []) +
+     (["-DIRE_PC_TICKS"] if os.environ.get("IRE_RB_ABLATE") == "2" else [])),
     ("gn.hip", []),
     ("fusion.hip", []),
     ("preprocess.hip", []),

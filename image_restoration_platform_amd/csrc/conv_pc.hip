@@ -44,6 +44,9 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #define C3_TEPI 0    // 1: C = 32 line-coalesced epilogue through a wave-private LDS transpose patch (build-time A/B).  Measured NEUTRAL (same box, twice
                      // each: RB2 314.3 / 318.8 vs 314.8 / 315.3 us, RB1 265.0 / 271.0 vs 266.6 / 267.5): the addresser's busy cycles fall, the kernel's time does not
 #endif
+#ifndef C3_TEPI64
+#define C3_TEPI64 1  // C = 64: line-coalesced epilogue through the item's released input tile (0: the direct epilogue; build-time A/B)
+#endif
 #ifndef C3_ABL
 #define C3_ABL 0     // timing ablations (results wrong by design): 1 no transform, 2 no epilogue, 4 no MFMA loop, 8 no input loads, 16 no output stores, 32 no statistics, 64 no residual loads
 #endif
@@ -70,7 +73,8 @@ template <int C> struct PcCfg {
     static constexpr int COEF_OFF = RED_OFF + 2 * RED_HALF * 4;
     static constexpr int HEAD_OFF = COEF_OFF + COEF_IMGS * C * 2 * 4;           // head: [8 waves][in | out][2 rows][96 B]
     static constexpr int PATCH_OFF = HEAD_OFF + (C == 32 ? 8 * 2 * 2 * 96 : 0);   // C = 32: [8 waves][32 pixels x 64 B] transpose patches of the line-coalesced epilogue
-    static constexpr int LDS = PATCH_OFF + (C == 32 ? 8 * 2048 : 0);
+    static constexpr int CNT_OFF = PATCH_OFF + (C == 32 ? 8 * 2048 : 0);          // C = 64: the consumers' rendezvous counter (16 B)
+    static constexpr int LDS = CNT_OFF + (C == 64 ? 16 : 0);
     static_assert(LDS <= 160 * 1024, "LDS");
     static_assert(!STREAM || W_STAGE_CHUNKS == 9 * C3_PROD, "a producer thread streams 9 weight chunks per stage");
 };
@@ -105,6 +109,17 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
+    // diagnostic build (IRE_RB_ABLATE=2, IRE_RB_STAMPS=<C>[r]): s_memtime stamps of consumer wave 0 and producer wave 8, per item
+    int stamp_item = 0;
+    auto stamp = [&](int k) {
+#ifdef IRE_PC_TICKS
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (a.stamps && lane == 0 && (wave == 0 || wave == 8) && blockIdx.x < 8 && stamp_item < 64)
+            a.stamps[(((size_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 64 + stamp_item) * 10 + k] = t;
+#else
+        (void)k;
+#endif
+    };
 
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     PersistCursor cursor(a.tiles_x, a.tiles_y, a.nimg, K::NBLK, NKC);   // item = (tile, 64-cout block); a cursor step is one 32-channel stage
@@ -119,6 +134,7 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
         uint4* wd = reinterpret_cast<uint4*>(smem + K::W_OFF);
         for (int i = tid; i < (K::STREAM ? 1 : NKC) * K::W_STAGE_CHUNKS; i += C3_THREADS) wd[i] = ws[i];
         if (tid < C) reinterpret_cast<float*>(smem + K::BIAS_OFF)[tid] = a.bias[tid];
+        if constexpr (C == 64) { if (tid == 0) *reinterpret_cast<unsigned*>(smem + K::CNT_OFF) = 0u; }
         // the GroupNorm+FiLM coefficients of the images this workgroup's items belong to (gn_fold just wrote them, or
         // gn_finalize_kernel did): the producers read them from LDS, so that their only VMEM traffic is the input stream
         const int nim = cursor.last_img - cursor.first_img + 1;                // <= COEF_IMGS (conv_pc_launch checks nimg)
@@ -293,11 +309,15 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
         c3_barrier();                                           // tile (and slab) of stage 0 are staged
         for (int t = 0; t < n_stages; ++t) {
             // tile / slab of stage t + 1 (for t + 1 == n_stages: the last stage again, into the slots nobody reads any more)
+            stamp_item = t / NKC;
+            stamp(3 * (t % NKC) + 0);
             load_coeffs(ls);
             wsrc = slab_of(ls);
             ls = cursor.next();
             transform_stage(smem + ((t + 1) & 1) * C3_IN_BYTES, smem + K::W_OFF + ((t + 1) & 1) * K::W_STAGE);   // the consumers finished reading these slots before the last barrier
+            stamp(3 * (t % NKC) + 1);
             c3_barrier();
+            stamp(3 * (t % NKC) + 2);
         }
         return;
     }
@@ -361,6 +381,13 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
     // global instruction of the epilogue is 1 KB contiguous.  Correct (same tests), and neutral in time: the addresser was busy,
     // not limiting.
     constexpr bool TEPI = C3_TEPI && C == 32 && !HEAD;
+    // C = 64 (TEPI64): the same transposition, with the patches in the input tile the item's LAST stage has just finished with (the
+    // kernel has no other 32 KB of LDS).  That tile belongs to the consumers until the stage barrier -- the producers are writing the
+    // other one -- but every consumer wave must be past its last fragment read first: the consumers meet on an LDS counter (no
+    // workgroup barrier: the producers must not wait here).  Why it pays at C = 64 and not at C = 32: here the item's stores sit on
+    // the critical path -- stamps (profiles/r03_experiments.md): the eight consumer waves issue their 64 partial-line stores
+    // together, ~66 addresser cycles each = 4 200 of the epilogue's 5 000 ticks, and the producers wait 4 000 ticks at the barrier.
+    constexpr bool TEPI64 = C3_TEPI64 && C == 64 && !HEAD && !K::STREAM;
     unsigned toffs[2];            // byte offset of (read-back pixel lane >> 2 of row m, chunk lane & 3) in the output image
     bool trow[2];
     int tcol = 0;
@@ -372,6 +399,8 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
     c3_barrier();                                               // tile of stage 0 is staged
     for (int t = 0; t < n_items; ++t) {
         const PersistItem it = cs.it;
+        stamp_item = t;
+        stamp(0);
         flush_stats();
         {   // output / residual offsets of this lane's two pixels; the residual rows are requested before the MFMAs
             const int oyb = it.ty * C3_TH + wave * 2, ox = it.tx * C3_TW + r;
@@ -383,15 +412,29 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
                 einb[m] = colok && oy < a.Hout;
                 eoffs[m] = ((unsigned)((min(oy, a.Hout - 1) * a.Wout + oxc) * C + it.nb * NT) << 1) + (unsigned)(h * 16);
             }
-            if constexpr (TEPI) {
-                tcol = it.tx * C3_TW + (lane >> 2);
+            if constexpr (TEPI || TEPI64) {
+                constexpr int LPP = C / 8;                  // lanes per pixel in the read-back layout: 4 (C = 32) / 8 (C = 64)
+                tcol = it.tx * C3_TW + lane / LPP;
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     const int oy = oyb + m;
                     trow[m] = oy < a.Hout;
-                    toffs[m] = ((unsigned)((min(oy, a.Hout - 1) * a.Wout + tcol) * C + 8 * (lane & 3)) << 1);
+                    toffs[m] = ((unsigned)((min(oy, a.Hout - 1) * a.Wout + tcol) * C + 8 * (lane % LPP)) << 1);
                 }
             }
+            if constexpr (RESID && TEPI64 && !(C3_ABL & 64)) {
+                // the residual rows in the read-back layout (1 KB = 8 pixels per request): RES_PRE of the 4 quarter-rows per row before the MFMAs
+                char* rbase = const_cast<char*>(reinterpret_cast<const char*>(a.resid)) + (size_t)it.img * a.Hout * a.Wout * (2 * C);
+                const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(rbase, 0, a.Hout * a.Wout * (2 * C), 0x00020000);
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int k = 0; k < RES_PRE; ++k) {
+                        const bool ok = trow[m] && tcol + 8 * k < a.Wout;
+                        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ok ? toffs[m] + (unsigned)(8 * k * 2 * C) : 0xffffffffu, 0, 0);
+                        erv[k][m] = make_uint4(v.x, v.y, v.z, v.w);
+                    }
+            } else
             if constexpr (RESID && TEPI && !(C3_ABL & 64)) {
                 // the residual rows in the read-back layout: two 1-KB requests per row, before the MFMAs
                 char* rbase = const_cast<char*>(reinterpret_cast<const char*>(a.resid)) + (size_t)it.img * a.Hout * a.Wout * (2 * C);
@@ -481,9 +524,21 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
             else if constexpr (NKC == 2) { if (kc & 1) stage_body(std::integral_constant<int, 1>{}); else stage_body(std::integral_constant<int, 0>{}); }   // (an item starts on an even stage)
             else stage_body(std::integral_constant<int, -1>{});
             ++stage_no;
-            if (kc + 1 < NKC) { cs = cursor.next(); c3_barrier(); }      // the item's next stage: its tile is staged, this one is free
+            stamp(kc == 0 ? 1 : 3);
+            if (kc + 1 < NKC) { cs = cursor.next(); c3_barrier(); stamp(2); }      // the item's next stage: its tile is staged, this one is free
         }
-        if constexpr (RESID && RES_PRE < 2 * NTL) {
+        if constexpr (RESID && TEPI64 && RES_PRE < 2 * NTL) {
+            char* rbase = const_cast<char*>(reinterpret_cast<const char*>(a.resid)) + (size_t)it.img * a.Hout * a.Wout * (2 * C);
+            const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(rbase, 0, a.Hout * a.Wout * (2 * C), 0x00020000);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int k = RES_PRE; k < 2 * NTL; ++k) {
+                    const bool ok = trow[m] && tcol + 8 * k < a.Wout;
+                    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ok ? toffs[m] + (unsigned)(8 * k * 2 * C) : 0xffffffffu, 0, 0);
+                    erv[k][m] = make_uint4(v.x, v.y, v.z, v.w);
+                }
+        } else if constexpr (RESID && RES_PRE < 2 * NTL) {
             // the rest of the residual rows: requested once the fragment registers are free (all of them before the MFMAs did not
             // fit 168 registers: 18 were spilled, and a scratch reload in the k-loop waits, in order, for the residual rows first);
             // the epilogue reaches them ~200 instructions later
@@ -520,6 +575,70 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int j = 0; j < NTL; ++j) asm volatile("" :: "v"(acc[m][j]));       // every accumulator stays live: no MFMA may be optimised away
+        } else if constexpr (TEPI64) {
+            char* obase = reinterpret_cast<char*>(a.out) + (size_t)it.img * a.Hout * a.Wout * (2 * C);
+            const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.Hout * a.Wout * (2 * C), 0x00020000);
+            const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+            float* redw = red_base + red_par * K::RED_HALF;
+            {   // consumers' rendezvous: the item's last tile (an item ends on an odd stage: tile 1) is free once all 8 waves are here
+                volatile unsigned* cnt = reinterpret_cast<volatile unsigned*>(smem + K::CNT_OFF);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(const_cast<unsigned*>(cnt), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned target = 8u * (unsigned)(t + 1);
+                while ((unsigned)__builtin_amdgcn_readfirstlane((int)*cnt) < target) __builtin_amdgcn_s_sleep(1);
+            }
+            unsigned char* patch = smem + C3_IN_BYTES + wave * 4096;       // [32 pixels][128 B], chunk index XOR (pixel & 7)
+            const int wsw = r & 7;                                         // writer: pixel r, chunks 2 g + h
+            const int pq = lane >> 3, cq = lane & 7;                       // reader: pixel pq + 8 k, chunk cq = couts 8 cq .. 8 cq + 7 = GroupNorm group cq
+            float sA = 0.f, qA = 0.f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int g = 0; g < 2 * NTL; ++g) {
+                    const f32x16_t& c = acc[m][g >> 1];
+                    const int pp = g & 1;
+                    const u32x4_t wv = {c3_pack(c[8 * pp + 0], c[8 * pp + 1]), c3_pack(c[8 * pp + 2], c[8 * pp + 3]),
+                                        c3_pack(c[8 * pp + 4], c[8 * pp + 5]), c3_pack(c[8 * pp + 6], c[8 * pp + 7])};
+                    *reinterpret_cast<u32x4_t*>(patch + r * 128 + (((2 * g + h) ^ wsw) << 4)) = wv;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int p = pq + 8 * k;
+                    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(patch + p * 128 + ((cq ^ (p & 7)) << 4));
+                    unsigned w[4] = {v.x, v.y, v.z, v.w};
+                    if constexpr (RESID) {
+                        const uint4 rr = erv[k][m];
+                        const unsigned rw[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) w[d] = c3_pack(c3_lo(w[d]) + c3_lo(rw[d]), c3_hi(w[d]) + c3_hi(rw[d]));
+                    }
+                    const bool ok = trow[m] && tcol + 8 * k < a.Wout;
+                    const float mf = ok ? 1.f : 0.f;
+                    float ts0 = 0.f, tq0 = 0.f;
+                    if constexpr (!(C3_ABL & 32))
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const bf16x2_t bv = __builtin_bit_cast(bf16x2_t, w[d]);
+                        ts0 = __builtin_amdgcn_fdot2_f32_bf16(bv, ones, ts0, false); tq0 = __builtin_amdgcn_fdot2_f32_bf16(bv, bv, tq0, false);
+                    }
+                    sA = __builtin_fmaf(ts0, mf, sA); qA = __builtin_fmaf(tq0, mf, qA);
+                    const u32x4_t o4 = {w[0], w[1], w[2], w[3]};
+                    if constexpr (C3_ABL & 16) asm volatile("" :: "v"(o4));
+                    else __builtin_amdgcn_raw_buffer_store_b128(o4, orsrc, ok ? toffs[m] + (unsigned)(8 * k * 2 * C) : 0xffffffffu, 0, 0);
+                }
+            }
+            if constexpr (!(C3_ABL & 32)) {
+                // the eight lanes that share a chunk sit 8 apart: one rotation within the row of 16, then the rows
+                float t2[2] = {sA, qA};
+#pragma unroll
+                for (int k = 0; k < 2; ++k) t2[k] = c3_ror_add<8>(t2[k]);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) t2[k] = c3_swap16_add(t2[k]);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) { float x = t2[k], y = t2[k]; asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y)); t2[k] = x + y; }
+                if (lane < 8) *reinterpret_cast<float4*>(redw + (wave * NCC + lane) * 4) = make_float4(t2[0], t2[1], 0.f, 0.f);
+            }
+            st_img = it.img; st_tile = it.tile; st_nb = it.nb; st_par = red_par; red_par ^= 1;
         } else if constexpr (TEPI) {
             char* obase = reinterpret_cast<char*>(a.out) + (size_t)it.img * a.Hout * a.Wout * (2 * C);
             const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.Hout * a.Wout * (2 * C), 0x00020000);
@@ -655,8 +774,10 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
             }
             st_img = it.img; st_tile = it.tile; st_nb = it.nb; st_par = red_par; red_par ^= 1;
         }
+        stamp(NKC == 1 ? 3 : 4);
         cs = cursor.next();
         c3_barrier();
+        stamp(5);
     }
     flush_stats();
 }

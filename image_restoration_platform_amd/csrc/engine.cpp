@@ -149,6 +149,8 @@ Engine::~Engine() {
                     long long d45 = (long long)(t[5] - t[4]);
                     if (t[6]) std::fprintf(stderr, "      k-steps 0..3=%lld  vmcnt wait=%lld  k-steps 4..8=%lld\n",
                                            (long long)(t[6] - t[0]), (long long)(t[7] - t[6]), (long long)(t[1] - t[7]));
+                    std::fprintf(stderr, "      raw deltas t1-t0..t5-t4: %lld %lld %lld %lld %lld\n", (long long)(t[1] - t[0]), (long long)(t[2] - t[1]),
+                                 (long long)(t[3] - t[2]), (long long)(t[4] - t[3]), (long long)(t[5] - t[4]));
                     if (t[3] && t[8]) std::fprintf(stderr, "      epilogue: barrier A=%lld  passes=%lld  reduce+red=%lld\n",
                                                    (long long)(t[8] - t[3]), (long long)(t[9] - t[8]), (long long)(t[4] - t[9]));
                     std::fprintf(stderr, "  s%02d %s=%lld %s=%lld %s=%lld %s=%lld %s=%lld | stage=%lld\n", s, names[0], d01, names[1], d12,
