@@ -23,7 +23,8 @@ SOURCES = [
      (["-DIRE_W4_TICKS"] if os.environ.get("IRE_RB_ABLATE") == "2" else []) +
      (["-DW4_TEPI=" + os.environ["IRE_W4_TEPI"]] if os.environ.get("IRE_W4_TEPI") else [])),
     ("conv_up.hip", (["-DIRE_UP_ABL=" + os.environ["IRE_UP_ABL"]] if os.environ.get("IRE_UP_ABL") else []) +
-     (["-DIRE_UP_D=" + os.environ["IRE_UP_D"]] if os.environ.get("IRE_UP_D") else [])),
+     (["-DIRE_UP_D=" + os.environ["IRE_UP_D"]] if os.environ.get("IRE_UP_D") else []) +
+     (["-DIRE_UP_TEPI=" + os.environ["IRE_UP_TEPI"]] if os.environ.get("IRE_UP_TEPI") else [])),
     ("conv_down.hip", []),
     ("conv_stem.hip", []),
     ("conv_f8.hip", []),

@@ -39,6 +39,9 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
+#ifndef IRE_UP_TEPI
+#define IRE_UP_TEPI 1     // fused form: line-coalesced epilogue (skip rows and output rows through a wave-private LDS patch); 0: the direct epilogue (build-time A/B)
+#endif
 #ifndef IRE_UP_ABL
 #define IRE_UP_ABL 0      // timing ablations of the fused epilogue (results wrong by design): 1 no skip term, 2 no statistics, 4 no stores, 8 L2 touches in the last stage
 #endif
@@ -58,6 +61,7 @@ constexpr int UP_SKW_OFF = UP_BIAS_OFF + 256 * 4;      // fused form: skip weigh
 constexpr int UP_RED_OFF = UP_SKW_OFF + 8192;          // fused form: [8 waves][8 cout quads][2] floats
 constexpr int UP_LDS = UP_RED_OFF + 8 * 8 * 2 * 4;
 static_assert(UP_LDS <= 160 * 1024, "LDS");
+constexpr int UP_PATCH = UP_BUF / 8;                   // line-coalesced epilogue: 9 KB per wave of the buffer the item's last stage has finished with
 
 __device__ __forceinline__ unsigned up_pack(float a, float b) {
     f32x2_t f = {a, b};
@@ -298,6 +302,138 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
             for (int m = 0; m < 2; ++m) asm volatile("" : "=v"(acc[par][m]));     // dead until the next item
     };
 
+    // ---- fused form, line-coalesced epilogue (IRE_UP_TEPI).  The direct epilogue below fetches the skip pixels in the MFMA B layout
+    // and stores from the accumulator layout: lane = pixel, so the four lanes of a quad address four different pixels and the
+    // texture addresser -- which coalesces within a quad -- spends ~100 cycles on such a load and ~66 on such a store instead of
+    // ~16-20 (profiles/r03_experiments.md): 21 000 / 34 000 / 60 000 addresser cycles per item at levels 0 / 1 / 2, half of the
+    // kernel, all in a phase where nothing else runs.  Here a wave works through its four output rows (m, pa); per row
+    //   * the skip row segment (64 pixels x 32 channels per piece) is loaded COALESCED (a quad = 64 contiguous bytes), written to
+    //     the wave's LDS patch (chunk index XOR-swizzled by the pixel pair) and read back as B fragments (2-way bank conflicts at
+    //     worst: a parity's pixels sit 2 apart) for the skip MFMAs of both column parities; the next piece's loads are in flight meanwhile;
+    //   * the two finished accumulator tiles (pb = 0, 1) go through the same patch the other way: written in the accumulator layout,
+    //     read back four lanes per pixel, GroupNorm partials per 8-cout chunk, stored 64 contiguous bytes per quad.
+    // The patch is the wave's ninth of the LDS buffer the item's last stage has just finished with, so the stage barrier comes BEFORE
+    // this epilogue; the barrier that publishes the partials closes it (the same two barriers per item as before).
+    auto epilogue_t = [&](const UpItem& it) __attribute__((always_inline)) {
+        constexpr int C = 16 * (NKS > 0 ? NKS : 2);      // skip channels = cout (the plain-up instantiation NKS = 0 never calls this)
+        constexpr int PCH = 32;                          // skip channels per piece: a quad of lanes = one pixel's 64 contiguous bytes (64-channel pieces: 16-21 spills)
+        constexpr int NPIECE = C / PCH;                  // 1, 2, 4 (levels 0, 1, 2)
+        constexpr int CPP = PCH / 8;                     // 16-B chunks per pixel in a piece: 4 or 8 = wave-loads per piece
+        constexpr int KSP = PCH / 16;                    // skip k-steps per piece: 2 or 4
+        constexpr int PSTEP = 64 / CPP;                  // pixels per wave-load: 16 or 8
+        int l_e = lane, w_e = wave;
+        asm volatile("" : "+v"(l_e), "+v"(w_e));
+        const int r_e = l_e & 31, h_e = l_e >> 5;
+        unsigned char* patch = smem + UP_BUF + w_e * UP_PATCH;          // an item ends on an odd stage: buffer 1
+        char* obase = reinterpret_cast<char*>(a.out) + (size_t)it.img * a.Hout * a.Wout * C * 2;
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.Hout * a.Wout * C * 2, 0x00020000);
+        const char* sbase = reinterpret_cast<const char*>(a.in1) + (size_t)it.img * a.Hout * a.Wout * C * 2;
+        const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(sbase), 0, a.Hout * a.Wout * C * 2, 0x00020000);
+        const int ly = it.ty * UP_TH + w_e * 2, ox0 = 2 * it.tx * UP_TW;
+        const unsigned char* skw = smem + UP_SKW_OFF + (h_e * 32 + r_e) * 16;      // + ks * 1024
+        const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+        // loader: chunk q = lane + 64 i of the piece = (pixel q / CPP, chunk q % CPP); 64 % CPP == 0, so the chunk is the lane's own
+        const int lc = l_e % CPP, lp0 = l_e / CPP;
+        const unsigned ld_lds = (unsigned)(lp0 * (CPP * 16) + ((lc ^ ((lp0 >> 1) & (CPP - 1))) << 4));      // + i * PSTEP * CPP * 16 (PSTEP is even: the swizzle term is i-invariant)
+        // store read-back: q = lane + 64 k = (pixel (lane >> 2) + 16 k, chunk lane & 3)
+        const int sp0 = l_e >> 2, scq = l_e & 3;
+        float ssum[2] = {0.f, 0.f}, qsum[2] = {0.f, 0.f};       // the two cout quads of this lane's read-back chunk: couts 8 scq .. +3, +4 .. +7
+        u32x4_t sk[CPP];
+        auto issue_piece = [&](int rr, int pc) __attribute__((always_inline)) {
+            const int m = rr >> 1, pa = rr & 1;
+            const int oy = 2 * (ly + m) + pa;
+            const bool rowok = ly + m < a.Hin;
+#pragma unroll
+            for (int i = 0; i < CPP; ++i) {
+                const int p = lp0 + i * PSTEP;
+                const bool ok = rowok && ox0 + p < a.Wout;
+                sk[i] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, ok ? (unsigned)(((oy * a.Wout + ox0 + p) * C + pc * PCH + lc * 8) * 2) : 0xffffffffu, 0, 0);
+            }
+        };
+        if constexpr (!(IRE_UP_ABL & 1)) issue_piece(0, 0);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int m = rr >> 1, pa = rr & 1;
+            if constexpr (!(IRE_UP_ABL & 1))
+#pragma unroll
+            for (int pc = 0; pc < NPIECE; ++pc) {
+#pragma unroll
+                for (int i = 0; i < CPP; ++i) *reinterpret_cast<u32x4_t*>(patch + ld_lds + i * (PSTEP * CPP * 16)) = sk[i];
+                if (rr * NPIECE + pc + 1 < 4 * NPIECE) issue_piece((rr * NPIECE + pc + 1) / NPIECE, (rr * NPIECE + pc + 1) % NPIECE);     // in flight across this piece's MFMAs (and the row's stores)
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                    for (int k = 0; k < KSP; ++k) {
+                        const bf16x8_t wk = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(skw + (pc * KSP + k) * 1024));
+                        const bf16x8_t fr = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(patch + (2 * r_e + pb) * (CPP * 16) + (((2 * k + h_e) ^ (r_e & (CPP - 1))) << 4)));
+                        acc[pa * 2 + pb][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk, fr, acc[pa * 2 + pb][m], 0, 0, 0);
+                    }
+            }
+            // ---- the row's two accumulator tiles -> patch (accumulator layout) -> read back four lanes per pixel -> statistics, stores
+            const int oy = 2 * (ly + m) + pa;
+            const bool rowok = ly + m < a.Hin;
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                const f32x16_t& c = acc[pa * 2 + pb][m];
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    const u32x4_t wv = {up_pack(c[8 * pp + 0], c[8 * pp + 1]), up_pack(c[8 * pp + 2], c[8 * pp + 3]),
+                                        up_pack(c[8 * pp + 4], c[8 * pp + 5]), up_pack(c[8 * pp + 6], c[8 * pp + 7])};
+                    *reinterpret_cast<u32x4_t*>(patch + (2 * r_e + pb) * 64 + (((2 * pp + h_e) ^ (r_e & 3)) << 4)) = wv;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int p = sp0 + 16 * k;
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(patch + p * 64 + ((scq ^ ((p >> 1) & 3)) << 4));
+                const bool ok = rowok && ox0 + p < a.Wout;
+                const unsigned w[4] = {v.x, v.y, v.z, v.w};
+                if constexpr (!(IRE_UP_ABL & 2))
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const bf16x2_t bv = __builtin_bit_cast(bf16x2_t, ok ? w[d] : 0u);      // the statistics are those of the STORED values
+                    ssum[d >> 1] = __builtin_amdgcn_fdot2_f32_bf16(bv, ones, ssum[d >> 1], false);
+                    qsum[d >> 1] = __builtin_amdgcn_fdot2_f32_bf16(bv, bv, qsum[d >> 1], false);
+                }
+                if constexpr (!(IRE_UP_ABL & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ok ? (unsigned)(((oy * a.Wout + ox0 + p) * C + it.nb * UP_NT + scq * 8) * 2) : 0xffffffffu, 0, 0);
+                else asm volatile("" :: "v"(v));
+            }
+        }
+        if constexpr (!(IRE_UP_ABL & 2)) {
+            // the 16 lanes that share a read-back chunk sit 4 apart: two rotations within the row of 16, then the rows and the halves
+            float rv[4] = {ssum[0], qsum[0], ssum[1], qsum[1]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rv[i] = up_ror_add<4>(rv[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rv[i] = up_ror_add<8>(rv[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rv[i] = up_swap16_add(rv[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { float x = rv[i], y = rv[i]; asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y)); rv[i] = x + y; }
+            float* red = reinterpret_cast<float*>(smem + UP_RED_OFF);
+            if (l_e < 4) {          // chunk scq = lane: cout quads 2 scq, 2 scq + 1
+                *reinterpret_cast<float2*>(red + (w_e * 8 + 2 * l_e) * 2) = make_float2(rv[0], rv[1]);
+                *reinterpret_cast<float2*>(red + (w_e * 8 + 2 * l_e + 1) * 2) = make_float2(rv[2], rv[3]);
+            }
+            __syncthreads();
+            const int G = a.group_size, qpg = G >> 2, ngl = UP_NT / G;       // quads per group (1, 2 or 4), groups in the item's 32 couts
+            if (tid < ngl) {
+                float sv = 0.f, qv = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < qpg) { sv += red[(w * 8 + tid * qpg + k) * 2 + 0]; qv += red[(w * 8 + tid * qpg + k) * 2 + 1]; }
+                float* st = a.stats + (((size_t)it.img * tiles_per_img + it.tile) * 8 + (it.nb * UP_NT) / G + tid) * 2;
+                st[0] = sv; st[1] = qv;
+            }
+        } else __syncthreads();
+#pragma unroll
+        for (int par = 0; par < 4; ++par)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) asm volatile("" : "=v"(acc[par][m]));     // dead until the next item
+    };
+
     // ---- one pipeline stage ------------------------------------------------------------------------------------------
     auto init_acc = [&](int nb) {            // new item: the accumulators start at the bias (permuted rows: cout 16*(i>>3) + 8h + (i&7))
         const float* bl = bias_lds + nb * UP_NT + 8 * h;
@@ -414,8 +550,13 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
         // the stage's one wait: the s+2 reloads and the DMA'd slab of s+1 (and the previous item's output stores)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (PREFETCH) asm volatile("" :: "v"(pf_dummy));      // the touches' destination register stayed reserved until here
-        if constexpr (LAST) epilogue(sq0.it);
-        __syncthreads();
+        if constexpr (LAST && NKS > 0 && IRE_UP_TEPI) {
+            __syncthreads();              // the stage barrier first: the finished buffer becomes the waves' patches
+            epilogue_t(sq0.it);           // ends with the barrier that publishes the partials: nobody restages that buffer before it
+        } else {
+            if constexpr (LAST) epilogue(sq0.it);
+            __syncthreads();
+        }
         sq0 = sq1; sq1 = sq2; sq2 = cursor.next();
     };
 
