@@ -47,10 +47,19 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #ifndef C3_TEPI64
 #define C3_TEPI64 1  // C = 64: line-coalesced epilogue through the item's released input tile (0: the direct epilogue; build-time A/B)
 #endif
+#ifndef C3_PROD8
+#define C3_PROD8 0   // 1: C = 32 ResBlock convs with EIGHT producer waves (16 waves per CU = four per SIMD, 128 registers each) instead of four
+                     // (build-time A/B).  Stamps: at C = 32 the four producers need 6 300-8 700 ticks for an item's tile while the consumers'
+                     // k-loop takes 2 300 and their epilogue ~3 000: the item waits for its producers.  Twice the producer waves: RB1 257.1 / 255.6
+                     // vs 260.5 / 259.8 us, RB2 313.9 / 317.2 vs 319.9 / 315.0 (same box): nothing -- the SIMD's vector issue is what the producers'
+                     // transform and the epilogues fill (85 % busy: profiles/r02_experiments.md), not a wave's own speed.  Off.
+#endif
 #ifndef C3_ABL
 #define C3_ABL 0     // timing ablations (results wrong by design): 1 no transform, 2 no epilogue, 4 no MFMA loop, 8 no input loads, 16 no output stores, 32 no statistics, 64 no residual loads
 #endif
 constexpr int C3_CONS = 512, C3_PROD = 256, C3_THREADS = C3_CONS + C3_PROD;
+// producer threads of an instantiation: 512 for the C = 32 ResBlock convs (C3_PROD8), 256 otherwise
+constexpr int pc_prod(int C, bool head) { return (C3_PROD8 && C == 32 && !head) ? 512 : 256; }
 constexpr int C3_TH = 16, C3_TW = 32, C3_IH = C3_TH + 2, C3_IW = C3_TW + 2;
 constexpr int C3_IN_CHUNKS = C3_IH * C3_IW * 4;                                 // 2448 x 16 B (32 channels per pixel and stage)
 constexpr int C3_P_ITERS = (C3_IN_CHUNKS + C3_PROD - 1) / C3_PROD;               // 10 chunks per producer thread and stage
@@ -101,8 +110,12 @@ __device__ __forceinline__ float c3_swap16_add(float v) {       // see conv_rb.h
 __device__ __forceinline__ void c3_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int C, bool RESID, bool HEAD>
-__global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
+__global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(ConvArgs a) {
     using K = PcCfg<C>;
+    constexpr int PROD = pc_prod(C, HEAD), THREADS = C3_CONS + PROD;
+    constexpr int P_ITERS = (C3_IN_CHUNKS + PROD - 1) / PROD;        // chunks per producer thread and stage: 10 or 5 (P_ITERS * PROD * 16 == C3_IN_BYTES either way)
+    static_assert(P_ITERS * PROD * 16 == C3_IN_BYTES, "tile slots");
+    static_assert(!K::STREAM || PROD == C3_PROD, "the streamed-weights form is written for four producer waves");
     constexpr int NKC = K::NKC, NTL = K::NTL, NCC = K::NCC, NT = K::NT;
     static_assert(!HEAD || C == 32, "the head is a C = 32 layer");
     __shared__ __attribute__((aligned(16))) unsigned char smem[K::LDS];
@@ -132,7 +145,7 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
         // resident weights: all of them; streamed: the slab of this workgroup's first stage (slot 0), the producers do the rest
         const uint4* ws = reinterpret_cast<const uint4*>(a.w) + (K::STREAM ? (size_t)cursor.cur.it.nb * NKC * K::W_STAGE_CHUNKS : 0);
         uint4* wd = reinterpret_cast<uint4*>(smem + K::W_OFF);
-        for (int i = tid; i < (K::STREAM ? 1 : NKC) * K::W_STAGE_CHUNKS; i += C3_THREADS) wd[i] = ws[i];
+        for (int i = tid; i < (K::STREAM ? 1 : NKC) * K::W_STAGE_CHUNKS; i += THREADS) wd[i] = ws[i];
         if (tid < C) reinterpret_cast<float*>(smem + K::BIAS_OFF)[tid] = a.bias[tid];
         if constexpr (C == 64) { if (tid == 0) *reinterpret_cast<unsigned*>(smem + K::CNT_OFF) = 0u; }
         // the GroupNorm+FiLM coefficients of the images this workgroup's items belong to (gn_fold just wrote them, or
@@ -140,7 +153,7 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
         const int nim = cursor.last_img - cursor.first_img + 1;                // <= COEF_IMGS (conv_pc_launch checks nimg)
         const float2* ab = a.ab + (size_t)cursor.first_img * C;
         float2* cd = reinterpret_cast<float2*>(smem + K::COEF_OFF);
-        for (int i = tid; i < nim * C; i += C3_THREADS) cd[i] = ab[i];
+        for (int i = tid; i < nim * C; i += THREADS) cd[i] = ab[i];
     }
     __syncthreads();
 
@@ -152,20 +165,20 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
 #endif
         const int tp = tid - C3_CONS;
         const int c8 = tp & 3;                                   // this thread always stages the same 8-channel slice of a pixel
-        // chunk i of this thread: halo-tile pixel p = (tp + 256 i) >> 2 -- constant for the whole kernel
-        int rel[C3_P_ITERS], lds_off[C3_P_ITERS];
-        unsigned pyx[C3_P_ITERS];
+        // chunk i of this thread: halo-tile pixel p = (tp + PROD i) >> 2 -- constant for the whole kernel
+        int rel[P_ITERS], lds_off[P_ITERS];
+        unsigned pyx[P_ITERS];
 #pragma unroll
-        for (int i = 0; i < C3_P_ITERS; ++i) {
-            const int q = tp + i * C3_PROD;
+        for (int i = 0; i < P_ITERS; ++i) {
+            const int q = tp + i * PROD;
             const int p = q >> 2;
             const int py = p / C3_IW, px = p - py * C3_IW;       // py == 18: a slot past the tile (LDS padding), never valid
             pyx[i] = ((unsigned)py << 8) | (unsigned)px;
             rel[i] = (py * a.Win + px) * (2 * C) + c8 * 16;
             lds_off[i] = (p * 4 + (c8 ^ ((p >> 2) & 3))) * 16;
         }
-        uint4 R[C3_P_ITERS];
-        unsigned okm[C3_P_ITERS];         // all ones / zero: the chunk in R[i] lies inside the image (travels with the data)
+        uint4 R[P_ITERS];
+        unsigned okm[P_ITERS];         // all ones / zero: the chunk in R[i] lies inside the image (travels with the data)
         float cA[8], cB[8];
         // raw rows of stage `ls` (item, 32-channel slice), requested chunk by chunk (load_chunk), and its coefficients (from LDS)
         PersistStage ls = cursor.cur;
@@ -225,11 +238,14 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
             w_issue(std::integral_constant<int, 0>{}); w_issue(std::integral_constant<int, 1>{});
             auto pair = [&](auto pp_tag) __attribute__((always_inline)) {
                 constexpr int pp_ = decltype(pp_tag)::value, i = 2 * pp_;
-                const unsigned wds[8] = {R[i].x, R[i].y, R[i].z, R[i].w, R[i + 1].x, R[i + 1].y, R[i + 1].z, R[i + 1].w};
+                constexpr int NCH = i + 1 < P_ITERS ? 2 : 1;              // chunks in this group (the last group of an odd P_ITERS is a single chunk)
+                constexpr int NW = 4 * NCH, NV = 8 * NCH;
+                constexpr int i1 = NCH == 2 ? i + 1 : i;
+                const unsigned wds[8] = {R[i].x, R[i].y, R[i].z, R[i].w, R[i1].x, R[i1].y, R[i1].z, R[i1].w};
                 unsigned o[8];
                 if constexpr (C3_ABL & 1) {
 #pragma unroll
-                    for (int w = 0; w < 8; ++w) o[w] = wds[w];
+                    for (int w = 0; w < NW; ++w) o[w] = wds[w];
                 } else {
 #if C3_SCALAR
                     // plain f32 instructions, one channel each (build flag -fno-slp-vectorize keeps them so): beside the consumers'
@@ -237,26 +253,27 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
                     // constants; measured here: profiles/r02_experiments.md)
                     float y[16], e[16];
 #pragma unroll
-                    for (int w = 0; w < 8; ++w) {
+                    for (int w = 0; w < NW; ++w) {
                         const int d = w & 3;
                         y[2 * w] = __builtin_fmaf(c3_lo(wds[w]), cA[2 * d], cB[2 * d]);
                         y[2 * w + 1] = __builtin_fmaf(c3_hi(wds[w]), cA[2 * d + 1], cB[2 * d + 1]);
                     }
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) e[k] = y[k] * (-1.4426950408889634f);
+                    for (int k = 0; k < NV; ++k) e[k] = y[k] * (-1.4426950408889634f);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) e[k] = __builtin_amdgcn_exp2f(e[k]);
+                    for (int k = 0; k < NV; ++k) e[k] = __builtin_amdgcn_exp2f(e[k]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) e[k] = e[k] + 1.0f;
+                    for (int k = 0; k < NV; ++k) e[k] = e[k] + 1.0f;
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) e[k] = __builtin_amdgcn_rcpf(e[k]);
+                    for (int k = 0; k < NV; ++k) e[k] = __builtin_amdgcn_rcpf(e[k]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int w = 0; w < 8; ++w) o[w] = c3_pack(y[2 * w] * e[2 * w], y[2 * w + 1] * e[2 * w + 1]);
+                    for (int w = 0; w < NW; ++w) o[w] = c3_pack(y[2 * w] * e[2 * w], y[2 * w + 1] * e[2 * w + 1]);
 #else
+                    static_assert(NCH == 2, "the packed-f32 form handles whole pairs");
                     f32x2_t y[8], e[8];
 #pragma unroll
                     for (int w = 0; w < 8; ++w) {
@@ -282,18 +299,19 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
 #endif
                 }
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
+                for (int k = 0; k < NCH; ++k) {
                     const unsigned m = okm[i + k];                                     // zero padding applies AFTER the activation
                     const uint4 ov = make_uint4(o[4 * k] & m, o[4 * k + 1] & m, o[4 * k + 2] & m, o[4 * k + 3] & m);
                     *reinterpret_cast<uint4*>(tile + lds_off[i + k]) = ov;
                 }
-                load_chunk(i); load_chunk(i + 1);
+                load_chunk(i);
+                if constexpr (NCH == 2) load_chunk(i + 1);
                 w_store(pp_tag, wslot);
                 if constexpr (pp_ + 2 < 5) w_issue(std::integral_constant<int, pp_ + 2>{});
                 __builtin_amdgcn_sched_barrier(0);
             };
             pair(std::integral_constant<int, 0>{}); pair(std::integral_constant<int, 1>{}); pair(std::integral_constant<int, 2>{});
-            pair(std::integral_constant<int, 3>{}); pair(std::integral_constant<int, 4>{});
+            if constexpr (P_ITERS > 6) { pair(std::integral_constant<int, 3>{}); pair(std::integral_constant<int, 4>{}); }
         };
         // stage 0 -> R; then every transform reloads R with the stage after (past the last stage the cursor stays on it: a
         // redundant reload of rows that are never used).  `ps` = the stage whose rows are in R = the stage being produced.
@@ -301,7 +319,7 @@ __global__ __launch_bounds__(C3_THREADS) void conv_pc_kernel(ConvArgs a) {
             return reinterpret_cast<const uint4*>(a.w) + ((size_t)st.it.nb * NKC + st.kc) * K::W_STAGE_CHUNKS;
         };
 #pragma unroll
-        for (int i = 0; i < C3_P_ITERS; ++i) load_chunk(i);
+        for (int i = 0; i < P_ITERS; ++i) load_chunk(i);
         load_coeffs(ls);
         wsrc = slab_of(ls);                                     // (slot 0 already holds it: the kernel prologue; written again, same bytes)
         ls = cursor.next();
@@ -816,7 +834,7 @@ void conv_pc_launch(bool resid, bool head, const ConvArgs& a, hipStream_t stream
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int grid = items < cus ? items : cus;
-#define PC_GO(CC, RS, HD) hipLaunchKernelGGL((conv_pc_kernel<CC, RS, HD>), dim3(grid), dim3(C3_THREADS), 0, stream, a)
+#define PC_GO(CC, RS, HD) hipLaunchKernelGGL((conv_pc_kernel<CC, RS, HD>), dim3(grid), dim3(C3_CONS + pc_prod(CC, HD)), 0, stream, a)
     if (head) PC_GO(32, false, true);
     else if (C == 32) { if (resid) PC_GO(32, true, false); else PC_GO(32, false, false); }
     else if (C == 64) { if (resid) PC_GO(64, true, false); else PC_GO(64, false, false); }
