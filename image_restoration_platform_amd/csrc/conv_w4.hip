@@ -95,7 +95,7 @@ struct W4Cfg {
     static constexpr int W_BASE = 2 * IN_BYTES;                // in[2] | w[3]
     static constexpr int MAIN_BYTES = W_BASE + 3 * W_BYTES;
     static constexpr int RED_BYTES = 2 * WAVES * 16 * 2 * 4;   // [item parity][waves][16 chunks of 8 couts][sum, sumsq]  (old epilogue: [waves][8 slots of 16 couts][2])
-    static constexpr int PATCH_BYTES = 16 * 256;               // line-coalesced epilogue: a wave's transpose patch (16 pixels x 128 couts) inside the stage's dead weight slab
+    static constexpr int PATCH_BYTES = 16 * NT * 2;            // line-coalesced epilogue: a wave's transpose patch (16 pixels x NT couts) inside the stage's dead weight slab
     static_assert(FP8 || WAVES * PATCH_BYTES <= W4_NSTEPS * 2 * NT * EB, "the patches live in one weight slab");
     static constexpr int BIAS_BYTES = 256 * 4;
     static constexpr int COEF_BYTES = WAVES * 128;             // FUSED: per wave, 16 channels x (A, B) of the stage being staged
@@ -300,17 +300,20 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
     unsigned toffs[C::MT];        // byte offset of (this lane's read-back pixel at q = 0, k = 0; its chunk c = lane & 15) in the output image
     bool trow[C::MT];
     int tcol0 = 0;
-    uint4 rvt[3][4];              // residual rows of pass (m, q) in slot pass % 3, read-back layout: 4 loads of 1 KB each
-    auto load_resid_pass = [&](int pass, uint4 (&dst)[4]) {
+    constexpr int NCHK = NT / 8;                  // 16-B chunks of a pixel's NT-cout run: 16 (NT = 128) or 8 (NT = 64)
+    constexpr int NRD = NCHK / 4;                 // read-backs (1 KB each) per 16-pixel pass: 4 or 2
+    constexpr int PPR = 64 / NCHK;                // pixels per read-back: 4 or 8
+    uint4 rvt[3][NRD];            // residual rows of pass (m, q) in slot pass % 3, read-back layout: NRD loads of 1 KB each
+    auto load_resid_pass = [&](int pass, uint4 (&dst)[NRD]) {
         if constexpr (RESID) {
             char* rbase = const_cast<char*>(reinterpret_cast<const char*>(a.resid)) + (size_t)sq0.it.img * a.Hout * a.Wout * a.cout * 2;
             const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(rbase, 0, a.Hout * a.Wout * a.cout * 2, 0x00020000);
             const int m = pass >> 1, q = pass & 1;
-            const unsigned cstep = (unsigned)a.cout * 8u;          // bytes per 4 pixels
+            const unsigned cstep = (unsigned)a.cout * 2u * PPR;    // bytes per read-back's PPR pixels
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const bool ok = trow[m] && tcol0 + 16 * q + 4 * k < a.Wout;
-                const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ok ? toffs[m] + (unsigned)(4 * q + k) * cstep : 0xffffffffu, 0, 0);
+            for (int k = 0; k < NRD; ++k) {
+                const bool ok = trow[m] && tcol0 + 16 * q + PPR * k < a.Wout;
+                const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ok ? toffs[m] + (unsigned)(NRD * q + k) * cstep : 0xffffffffu, 0, 0);
                 dst[k] = make_uint4(v.x, v.y, v.z, v.w);
             }
         }
@@ -330,12 +333,12 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
             asm volatile("" : "+v"(l_e), "+v"(w_e));
             cout0_e = it.nb * NT;
             const int oyb = it.ty * W4_TH + w_e * C::MT;
-            tcol0 = it.tx * W4_TW + (l_e >> 4);
+            tcol0 = it.tx * W4_TW + l_e / NCHK;
 #pragma unroll
             for (int m = 0; m < C::MT; ++m) {
                 const int oy = oyb + m;
                 trow[m] = oy < a.Hout;
-                toffs[m] = ((unsigned)((min(oy, a.Hout - 1) * a.Wout + tcol0) * a.cout + cout0_e + 8 * (l_e & 15)) << 1);
+                toffs[m] = ((unsigned)((min(oy, a.Hout - 1) * a.Wout + tcol0) * a.cout + cout0_e + 8 * (l_e % NCHK)) << 1);
             }
             load_resid_pass(0, rvt[0]);       // before the stage's MFMAs (k-steps 0..3 carry no other VMEM): landed when the epilogue starts
             return;
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
                 }
                 if constexpr (LAST && RESID && TEPI) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(rvt[0][k].x), "+v"(rvt[0][k].y), "+v"(rvt[0][k].z), "+v"(rvt[0][k].w));
+                    for (int k = 0; k < NRD; ++k) asm volatile("" : "+v"(rvt[0][k].x), "+v"(rvt[0][k].y), "+v"(rvt[0][k].z), "+v"(rvt[0][k].w));
                 } else if constexpr (LAST && RESID) {      // landed as well: tell the compiler, or it re-waits with its own (short) count
 #pragma unroll
                     for (int g = 0; g + 1 < RD; ++g)
@@ -622,7 +625,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
             for (int w = 0; w < WAVES; ++w)
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (k < cpg) { sv += rd[(w * 16 + tid * cpg + k) * 2 + 0]; qv += rd[(w * 16 + tid * cpg + k) * 2 + 1]; }
+                    if (k < cpg) { sv += rd[(w * NCHK + tid * cpg + k) * 2 + 0]; qv += rd[(w * NCHK + tid * cpg + k) * 2 + 1]; }
             float* st = a.stats + (((size_t)st_img * tiles_per_img + st_tile) * 8 + st_cout0 / G + tid) * 2;
             st[0] = sv; st[1] = qv;
         }
@@ -642,8 +645,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
         const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.Hout * a.Wout * a.cout * 2, 0x00020000);
         const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
         const int r16 = l_e & 15, qh = (l_e >> 4) & 1;                    // writer: pixel r = 16 qh + r16 of the row, half h
-        const int pq = l_e >> 4, cc_r = l_e & 15;                         // reader: pixel 4 k + pq of the half-row, chunk cc_r (8 couts)
-        const unsigned cstep = (unsigned)a.cout * 8u;
+        const int pq = l_e / NCHK, cc_r = l_e % NCHK;                     // reader: pixel PPR k + pq of the half-row, chunk cc_r (8 couts)
+        constexpr int PITCH = NT * 2;                                     // bytes of a pixel's run in the patch
+        const unsigned cstep = (unsigned)a.cout * 2u * PPR;
         float ssum = 0.f, qsum = 0.f;
 #pragma unroll
         for (int m = 0; m < C::MT; ++m)
@@ -667,14 +671,14 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
                                          w4_pack(c[8 * pp + 4], c[8 * pp + 5]), w4_pack(c[8 * pp + 6], c[8 * pp + 7])};
                         }
                         const int cc = 2 * g + h_e;                       // chunk of the pixel's 128-cout run: couts 8 cc .. 8 cc + 7
-                        *reinterpret_cast<u32x4_t*>(patch + r16 * 256 + ((cc ^ r16) << 4)) = wv;
+                        *reinterpret_cast<u32x4_t*>(patch + r16 * PITCH + ((cc ^ (r16 & (NCHK - 1))) << 4)) = wv;
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int p = 4 * k + pq;
-                    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(patch + p * 256 + ((cc_r ^ p) << 4));
+                for (int k = 0; k < NRD; ++k) {
+                    const int p = PPR * k + pq;
+                    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(patch + p * PITCH + ((cc_r ^ (p & (NCHK - 1))) << 4));
                     unsigned w[4] = {v.x, v.y, v.z, v.w};
                     if constexpr (RESID) {
                         const uint4 rr = rvt[(2 * m + q) % 3][k];
@@ -689,18 +693,19 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
                         s1 = __builtin_amdgcn_fdot2_f32_bf16(bv, ones, s1, false);
                         q1 = __builtin_amdgcn_fdot2_f32_bf16(bv, bv, q1, false);
                     }
-                    const bool ok = trow[m] && tcol0 + 16 * q + 4 * k < a.Wout && (!(DBG & 4) || w[0] == 0x12345678u);
+                    const bool ok = trow[m] && tcol0 + 16 * q + PPR * k < a.Wout && (!(DBG & 4) || w[0] == 0x12345678u);
                     ssum += ok ? s1 : 0.f; qsum += ok ? q1 : 0.f;
                     const u32x4_t o4 = {w[0], w[1], w[2], w[3]};
-                    __builtin_amdgcn_raw_buffer_store_b128(o4, orsrc, ok ? toffs[m] + (unsigned)(4 * q + k) * cstep : 0xffffffffu, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o4, orsrc, ok ? toffs[m] + (unsigned)(NRD * q + k) * cstep : 0xffffffffu, 0, 0);
                 }
                 if constexpr (RESID) { if (2 * m + q + 3 < 2 * C::MT) load_resid_pass(2 * m + q + 3, rvt[(2 * m + q) % 3]); }
             }
         stamp(9);
-        // this lane's chunk cc_r over its 16 read-backs; the other three lanes with the same chunk sit 16, 32, 48 lanes away
+        // this lane's chunk cc_r over its read-backs; the other lanes with the same chunk sit NCHK apart
+        if constexpr (NCHK == 8) { ssum = w4_ror_add<8>(ssum); qsum = w4_ror_add<8>(qsum); }
         ssum = w4_swap16_add(ssum); qsum = w4_swap16_add(qsum);
         ssum = w4_swap32_add(ssum); qsum = w4_swap32_add(qsum);
-        if (l_e < 16) *reinterpret_cast<float2*>(red + red_par * (WAVES * 32) + (wave * 16 + cc_r) * 2) = make_float2(ssum, qsum);
+        if (l_e < NCHK) *reinterpret_cast<float2*>(red + red_par * (WAVES * 32) + (wave * NCHK + cc_r) * 2) = make_float2(ssum, qsum);
         st_img = it.img; st_tile = it.tile; st_cout0 = cout0; st_par = red_par; red_par ^= 1;
     };
     auto finish = [&](int s) {
@@ -792,6 +797,7 @@ void conv_w4_launch(bool resid, const ConvArgs& a, hipStream_t stream) {
     }
     if (a.w4_waves == 4 && a.ab != nullptr) fail(IRE_ERR_INTERNAL, "internal: conv_w4 4-wave form has no fused activation");
     if (a.w4_waves == 4) { if (resid) launch_w4<128, 4, true, false>(a, stream); else launch_w4<128, 4, false, false>(a, stream); }
+    else if (a.ab != nullptr && a.w4_nt == 64) { if (resid) launch_w4<64, 8, true, false, 0, true>(a, stream); else launch_w4<64, 8, false, false, 0, true>(a, stream); }
     else if (a.ab != nullptr) { if (resid) launch_w4<128, 8, true, false, 0, true>(a, stream); else launch_w4<128, 8, false, false, 0, true>(a, stream); }
     else            { if (resid) launch_w4<128, 8, true, false>(a, stream); else launch_w4<128, 8, false, false>(a, stream); }
 }

@@ -87,6 +87,7 @@ Engine::Engine(const ire_config& cfg) {
     if (const char* v = std::getenv("IRE_ACT_SPLIT_MINC")) act_split_min_c_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_RB_PRIO")) prio_young_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_W4")) use_w4_ = std::atoi(v);
+    if (const char* v = std::getenv("IRE_W4_SPLIT")) w4_split_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_W4_WAVES")) w4_waves_ = std::atoi(v) == 4 ? 4 : 8;
     if (const char* v = std::getenv("IRE_W4_FUSED_MINC")) w4_fused_min_c_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_UP_RB_MINC")) up_rb_min_c_ = std::atoi(v);
@@ -330,6 +331,22 @@ ConvW Engine::make_conv(ConvKind kind, const std::string& wname, const std::stri
         c.d_w4 = (unsigned short*)dalloc(arr4.size() * 2);
         net_.allocs.push_back(c.d_w4);
         IRE_HIP(hipMemcpy(c.d_w4, arr4.data(), arr4.size() * 2, hipMemcpyHostToDevice));
+        {   // the same slabs in 64-cout blocks: [nblock (64 couts)][kc16][kk][64][8]
+            std::vector<unsigned short> arrh(arr4.size(), 0);
+            for (int nb = 0; nb < cout / 64; ++nb)
+                for (int kc = 0; kc < nk4; ++kc)
+                    for (int kk = 0; kk < 18; ++kk) {
+                        const int tap = kk >> 1, c8 = kk & 1;
+                        for (int n = 0; n < 64; ++n)
+                            for (int e = 0; e < 8; ++e) {
+                                const int co = nb * 64 + perm(n), ci = kc * 16 + c8 * 8 + e;
+                                arrh[((((size_t)nb * nk4 + kc) * 18 + kk) * 64 + n) * 8 + e] = f32_to_bf16(W[((size_t)co * cin + ci) * 9 + tap]);
+                            }
+                    }
+            c.d_w4h = (unsigned short*)dalloc(arrh.size() * 2);
+            net_.allocs.push_back(c.d_w4h);
+            IRE_HIP(hipMemcpy(c.d_w4h, arrh.data(), arrh.size() * 2, hipMemcpyHostToDevice));
+        }
         if (precision_ == IRE_PRECISION_FP8) {
             // the same slabs as OCP e4m3 with one scale per OUTPUT channel: w_q = e4m3(w / s_w[co]), s_w[co] = max|w[co]| / 448
             // (the whole e4m3 range per channel); activations are scaled by kActScale = 16 while staging (conv_w4.hip), so the
@@ -929,6 +946,15 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
         conv_f8_launch(cw.kind == CONV_RB2, a, R.stream); kname = "conv_f8";
     } else if (w4) {
         a.w = cw.d_w4; a.nkc = cw.cin / 16; a.nblocks = cw.cout / 128;
+        {   // 64-cout items where 128-cout ones would leave CUs idle (512^2 at level 3): twice the items, each half the MFMAs.  The choice
+            // is a function of the IMAGE's shape at this level only -- not of the batch size, not of the strip -- because the two forms add
+            // the GroupNorm partials of a tile in different fp32 orders: a result must not depend on the batch around it or on the strip
+            // decomposition (tests: batch invariance, tiled == untiled).  Rule: a batch of 8 such images would not fill the CUs.
+            const int tiles_img = ceil_div(g.H >> op.lout, kRbTileH) * ceil_div(g.w >> op.lout, 32);
+            if (w4_split_ && cw.d_w4h && a.ab != nullptr && cw.d_w8 == nullptr && a.w4_waves == 8 && tiles_img * a.nblocks * 8 < 256) {
+                a.w = cw.d_w4h; a.nblocks = cw.cout / 64; a.w4_nt = 64;
+            }
+        }
         if (cw.d_w8 != nullptr && a.ab != nullptr) {      // IRE_PRECISION_FP8: e4m3 operands for the C >= 128 ResBlock convs
             a.fp8 = 1; a.w = reinterpret_cast<const unsigned short*>(cw.d_w8); a.bias = cw.d_bias8; a.oscale = cw.d_oscale;
         }

@@ -29,6 +29,7 @@ struct ConvW {
     unsigned short* d_w = nullptr;
     unsigned short* d_wp = nullptr;   // slabs with permuted cout rows for conv_rb.hip's direct epilogue
     unsigned short* d_w4 = nullptr;  // second arrangement for conv_w4.hip (C >= 128 ResBlock convs): 16-channel stages, 128-cout blocks
+    unsigned short* d_w4h = nullptr; // the same in 64-cout blocks: launches whose 128-cout items number fewer than the CUs (small batches, 512^2 at level 3)
     unsigned short* d_wstem = nullptr;  // CONV_STEM as MFMA A fragments (conv_stem.hip): [ky 3][h 2][32 permuted rows][8], k = 16 ky + 4 kx + c (kx = 3, c = 3: zero)
     unsigned short* d_wd = nullptr;  // CONV_DOWN by pixel phase (conv_down.hip): [nblock64][kc32][phase: 1+2+2+4 taps][tap*4 + c8][64][8]
     unsigned short* d_wu = nullptr;  // CONV_UP as a sub-pixel conv (conv_up.hip): [nblock32][kc32][parity][kk][32][8], taps pre-summed per parity
@@ -218,6 +219,7 @@ private:
     int precision_ = IRE_PRECISION_BF16;
     int w4_fused_min_c_ = 128;      // IRE_W4_FUSED_MINC: ResBlock convs with fused activation and cout >= this run on conv_w4's fused variant
     int w4_waves_ = 8;            // IRE_W4_WAVES=4: the one-wave-per-SIMD form, pre-activated inputs only (fused activation needs the 8-wave form)
+    int w4_split_ = 1;            // IRE_W4_SPLIT=0: never use the 64-cout items
     int use_w4_ = 1;              // C >= 128 ResBlock convs on conv_w4.hip (IRE_W4=0: conv_rb.hip; IRE_W4_WAVES=4|8)
     int fp8_mx_ = 1;              // fp8: the block-scaled K = 64 MFMA (conv_f8.hip); IRE_FP8_MX=0: the same-rate 32x32x16 fp8 form in conv_w4.hip
     int down_rb_ = 1;             // stride-2 `down` convs on conv_down.hip's pipelined phase kernel (IRE_DOWN_RB=0: the v1 kernel)
