@@ -609,6 +609,11 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
             const int wsw = r & 7;                                         // writer: pixel r, chunks 2 g + h
             const int pq = lane >> 3, cq = lane & 7;                       // reader: pixel pq + 8 k, chunk cq = couts 8 cq .. 8 cq + 7 = GroupNorm group cq
             float sA = 0.f, qA = 0.f;
+            // Order of the passes: quarter-rows k = 0, 1 of BOTH rows first, then k = 2, 3 -- the residual quarter-rows k >= RES_PRE were
+            // requested only after the k-loop (registers), so they get the first half's arithmetic and stores to land.  A row goes
+            // through the patch once per half (4 more LDS stores per row, against an exposed memory latency per item).
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -620,7 +625,7 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
                     *reinterpret_cast<u32x4_t*>(patch + r * 128 + (((2 * g + h) ^ wsw) << 4)) = wv;
                 }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 2 * half; k < 2 * half + 2; ++k) {
                     const int p = pq + 8 * k;
                     const u32x4_t v = *reinterpret_cast<const u32x4_t*>(patch + p * 128 + ((cq ^ (p & 7)) << 4));
                     unsigned w[4] = {v.x, v.y, v.z, v.w};

@@ -11,6 +11,7 @@
 // FiLM: the 7 classifier scores condition the restoration (the reference conditions the
 // provider call on the classification: restorator.js:57-94): film = Wf * scores + bf, sliced per level.
 #include "gn.hpp"
+#include "gn_fold.hpp"
 
 #include <algorithm>
 
@@ -18,52 +19,14 @@ namespace ire {
 
 namespace {
 
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ stats, int ntiles, int C,
-                                                          int hw, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta,
-                                                          const float* __restrict__ film, int film_stride,
-                                                          int film_off, float2* __restrict__ ab) {
-    // one workgroup per (image, group): fixed-order tree reduction of the tile partials in double
-    __shared__ double red[256][2];
-    __shared__ float s_mean, s_rstd;
-    const int img = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
-    double s = 0.0, q = 0.0;
-    const float2* st = reinterpret_cast<const float2*>(stats) + (size_t)img * ntiles * 8 + g;
-    for (int t = tid; t < ntiles; t += 256) {
-        const float2 v = st[(size_t)t * 8];
-        s += (double)v.x;
-        q += (double)v.y;
-    }
-    red[tid][0] = s;
-    red[tid][1] = q;
-    __syncthreads();
-    for (int off = 128; off >= 1; off >>= 1) {
-        if (tid < off) { red[tid][0] += red[tid + off][0]; red[tid][1] += red[tid + off][1]; }
-        __syncthreads();
-    }
-    const int G = C / 8;
-    if (tid == 0) {
-        const double cnt = (double)hw * (double)G;
-        const double mean = red[0][0] / cnt;
-        double var = red[0][1] / cnt - mean * mean;
-        if (var < 0.0) var = 0.0;
-        s_mean = (float)mean;
-        s_rstd = (float)(1.0 / sqrt(var + 1e-5));
-    }
-    __syncthreads();
-    for (int k = tid; k < G; k += 256) {
-        const int c = g * G + k;
-        const float rg = s_rstd * gamma[c];
-        float sc = 0.f, sh = 0.f;
-        if (film) {
-            sc = film[(size_t)img * film_stride + film_off + c];
-            sh = film[(size_t)img * film_stride + film_off + C + c];
-        }
-        float2 o;
-        o.x = rg * (1.f + sc);
-        o.y = (beta[c] - s_mean * rg) * (1.f + sc) + sh;
-        ab[(size_t)img * C + c] = o;
-    }
+// The standalone finalize (row strips: one finalize over the gathered partials array; the A/B fallback kernels): ONE workgroup of
+// 512 threads per image running gn_fold -- the very function, with the very thread count, that the consuming convolutions run in
+// their prologues (gn_fold.hpp).  Same partials, same double-precision addition tree, same float arithmetic afterwards: the
+// coefficients are bit-identical to the folded finalize BY CONSTRUCTION, which is what makes a tiled run (this kernel) equal to
+// the untiled run (the folded prologue) bit for bit.
+__global__ __launch_bounds__(512) void gn_finalize_kernel(ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[512 * 16 + 64];
+    gn_fold(a, smem, blockIdx.x, blockIdx.x, 512);
 }
 
 // y = silu(x*A[n][c] + B[n][c]) as its own pass: used for the C >= 128 levels, where every input element
@@ -112,8 +75,10 @@ __global__ void film_kernel(const float* __restrict__ cond, const float* __restr
 void gn_finalize_launch(const float* d_stats, int nimg, int ntiles, int C, int hw, const float* d_gamma,
                         const float* d_beta, const float* d_film, int film_stride, int film_off,
                         float2* d_ab, hipStream_t stream) {
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(nimg, 8), dim3(256), 0, stream, d_stats, ntiles, C, hw, d_gamma,
-                       d_beta, d_film, film_stride, film_off, d_ab);
+    ConvArgs a{};
+    a.cin0 = C; a.gn_stats = d_stats; a.gn_parts = ntiles; a.gn_hw = hw; a.gn_gamma = d_gamma; a.gn_beta = d_beta;
+    a.gn_film = d_film; a.gn_film_stride = film_stride; a.gn_film_off = film_off; a.ab_w = d_ab;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(nimg), dim3(512), 0, stream, a);
     IRE_HIP(hipGetLastError());
 }
 

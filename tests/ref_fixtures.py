@@ -9,9 +9,12 @@ server-node/tests/utils/imageFixtures.js:5-45,91-93 step by step:
     createColorShiftedImage            : flat (220,80,40)                    -> JPEG q95
 
 and decoded again to the RGB the classifier sees.  The codec is PIL's, not sharp's (sharp / libvips cannot be
-installed here): quantisation tables and chroma subsampling follow libjpeg's defaults for those qualities, as
-sharp's do, but the bytes are not claimed identical -- the reference's assertions on these fixtures are
-inequalities (tests/classifierService.test.js:19-57), which is what they are used for.
+installed here): quantisation tables follow libjpeg's defaults for those qualities, as sharp's do.  Chroma subsampling
+does NOT match everywhere: PIL's default is 4:2:0 at every quality, sharp writes 4:4:4 from quality 90 up -- i.e. for the
+three q95 fixtures.  Those three are flat fields (every 8x8 block is DC-only in all three planes), so the decoded pixels do not
+depend on the subsampling; the q60 / q80 fixtures are 4:2:0 under both codecs.  The bytes are not claimed identical -- the
+reference's assertions on these fixtures are inequalities (tests/classifierService.test.js:19-57), which is what they are
+used for.
 """
 import io
 
