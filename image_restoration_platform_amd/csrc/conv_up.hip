@@ -314,6 +314,25 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
     //     read back four lanes per pixel, GroupNorm partials per 8-cout chunk, stored 64 contiguous bytes per quad.
     // The patch is the wave's ninth of the LDS buffer the item's last stage has just finished with, so the stage barrier comes BEFORE
     // this epilogue; the barrier that publishes the partials closes it (the same two barriers per item as before).
+    // the first skip piece of an item is requested BEFORE the stage barrier that precedes the epilogue (the barrier wait and the
+    // patch set-up then cover its latency: otherwise every item pays one exposed round trip)
+    u32x4_t skpre[4];
+    auto epi_prefetch = [&](const UpItem& it) __attribute__((always_inline)) {
+        constexpr int C = 16 * (NKS > 0 ? NKS : 2);
+        int l_e = lane, w_e = wave;
+        asm volatile("" : "+v"(l_e), "+v"(w_e));
+        const char* sbase = reinterpret_cast<const char*>(a.in1) + (size_t)it.img * a.Hout * a.Wout * C * 2;
+        const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(sbase), 0, a.Hout * a.Wout * C * 2, 0x00020000);
+        const int ly = it.ty * UP_TH + w_e * 2, ox0 = 2 * it.tx * UP_TW;
+        const int lc = l_e & 3, lp0 = l_e >> 2;
+        const bool rowok = ly < a.Hin;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = lp0 + i * 16;
+            const bool ok = rowok && ox0 + p < a.Wout;
+            skpre[i] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, ok ? (unsigned)((((2 * ly) * a.Wout + ox0 + p) * C + lc * 8) * 2) : 0xffffffffu, 0, 0);
+        }
+    };
     auto epilogue_t = [&](const UpItem& it) __attribute__((always_inline)) {
         constexpr int C = 16 * (NKS > 0 ? NKS : 2);      // skip channels = cout (the plain-up instantiation NKS = 0 never calls this)
         constexpr int PCH = 32;                          // skip channels per piece: a quad of lanes = one pixel's 64 contiguous bytes (64-channel pieces: 16-21 spills)
@@ -350,7 +369,10 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
                 sk[i] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, ok ? (unsigned)(((oy * a.Wout + ox0 + p) * C + pc * PCH + lc * 8) * 2) : 0xffffffffu, 0, 0);
             }
         };
-        if constexpr (!(IRE_UP_ABL & 1)) issue_piece(0, 0);
+        if constexpr (!(IRE_UP_ABL & 1)) {
+#pragma unroll
+            for (int i = 0; i < CPP; ++i) sk[i] = skpre[i];        // piece (row 0, channels 0..31): requested by epi_prefetch before the stage barrier
+        }
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int m = rr >> 1, pa = rr & 1;
@@ -551,6 +573,7 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (PREFETCH) asm volatile("" :: "v"(pf_dummy));      // the touches' destination register stayed reserved until here
         if constexpr (LAST && NKS > 0 && IRE_UP_TEPI) {
+            if constexpr (!(IRE_UP_ABL & 1)) epi_prefetch(sq0.it);
             __syncthreads();              // the stage barrier first: the finished buffer becomes the waves' patches
             epilogue_t(sq0.it);           // ends with the barrier that publishes the partials: nobody restages that buffer before it
         } else {
