@@ -128,11 +128,8 @@ function createEngineRestorer(opts) {
       }
       const png = await codec.encode({ data: crop(pixels, W, w, h), width: w, height: h });
       jobCounter += 1;
-      // the base64 of the encoded image off the JS thread (libuv pool; the JS thread only builds the string): V8's
-      // Buffer.toString('base64') of a raw 3-MB image is ~1 ms of the one JS thread per job
-      const b64 = engine.addon.base64Async && png.length >= 65536 ? await engine.addon.base64Async(png) : png.toString('base64');
       return {
-        base64Image: b64,
+        base64Image: png.toString('base64'),
         metadata: { providerRequestId: 'ire-' + process.pid + '-' + jobCounter, billedTokens: null, estimatedCostUsd: 0 },
       };
     },

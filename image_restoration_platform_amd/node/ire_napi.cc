@@ -356,67 +356,6 @@ napi_value preprocess_async(napi_env env, napi_callback_info info) {
     return promise;
 }
 
-// base64Async(buffer) -> Promise<string>: the result contract of the restoreImage seam is a base64 STRING (restorator.js:108).  V8's
-// Buffer.toString('base64') of a 3-MB image is ~1 ms on the one JS thread -- by itself a ~975 jobs/s bound on the whole seam.  Here the
-// encoding runs on the libuv pool and the JS thread only builds the string from the finished bytes (one copy into the V8 heap).
-struct B64Job {
-    const uint8_t* in = nullptr;      // the caller's Buffer, kept alive by `ref` (the adapter hands over a Buffer nobody writes to afterwards)
-    size_t n = 0;
-    napi_ref ref = nullptr;
-    std::string out;
-    napi_deferred deferred;
-    napi_async_work work;
-};
-void b64_execute(napi_env, void* data) {
-    B64Job* j = (B64Job*)data;
-    static const char T[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
-    const size_t n = j->n;
-    j->out.resize(((n + 2) / 3) * 4);
-    const uint8_t* p = j->in;
-    char* o = &j->out[0];
-    size_t i = 0;
-    for (; i + 2 < n; i += 3, o += 4) {
-        const unsigned v = ((unsigned)p[i] << 16) | ((unsigned)p[i + 1] << 8) | p[i + 2];
-        o[0] = T[v >> 18]; o[1] = T[(v >> 12) & 63]; o[2] = T[(v >> 6) & 63]; o[3] = T[v & 63];
-    }
-    if (i < n) {
-        const unsigned v = ((unsigned)p[i] << 16) | (i + 1 < n ? (unsigned)p[i + 1] << 8 : 0u);
-        o[0] = T[v >> 18]; o[1] = T[(v >> 12) & 63]; o[2] = i + 1 < n ? T[(v >> 6) & 63] : '='; o[3] = '=';
-    }
-}
-void b64_complete(napi_env env, napi_status, void* data) {
-    B64Job* j = (B64Job*)data;
-    napi_value str;
-    if (napi_create_string_latin1(env, j->out.data(), j->out.size(), &str) == napi_ok) napi_resolve_deferred(env, j->deferred, str);
-    else {
-        napi_value msg, err;
-        napi_create_string_utf8(env, "internal: cannot create the base64 string", NAPI_AUTO_LENGTH, &msg);
-        napi_create_error(env, nullptr, msg, &err);
-        napi_reject_deferred(env, j->deferred, err);
-    }
-    napi_delete_reference(env, j->ref);
-    napi_delete_async_work(env, j->work);
-    delete j;
-}
-napi_value base64_async(napi_env env, napi_callback_info info) {
-    size_t argc = 1; napi_value argv[1];
-    napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
-    void* data; size_t len; bool is_buf = false;
-    if (argc < 1 || napi_is_buffer(env, argv[0], &is_buf) != napi_ok || !is_buf || napi_get_buffer_info(env, argv[0], &data, &len) != napi_ok) {
-        throw_err(env, "invalid input: expected a Buffer");
-        return nullptr;
-    }
-    B64Job* j = new B64Job();
-    j->in = (const uint8_t*)data; j->n = len;
-    napi_create_reference(env, argv[0], 1, &j->ref);
-    napi_value promise, name;
-    napi_create_promise(env, &j->deferred, &promise);
-    napi_create_string_utf8(env, "ire-b64", NAPI_AUTO_LENGTH, &name);
-    napi_create_async_work(env, nullptr, name, b64_execute, b64_complete, j, &j->work);
-    napi_queue_async_work(env, j->work);
-    return promise;
-}
-
 // stats(engine) -> {queueDepth, batches, images, lastBatch, maxBatch, imagesPerSec}   (f4: health entry + images/sec gauge)
 napi_value stats_sync(napi_env env, napi_callback_info info) {
     size_t argc = 1; napi_value argv[1];
@@ -482,7 +421,6 @@ napi_value module_init(napi_env env, napi_value exports) {
         {"preprocessAsync", nullptr, preprocess_async, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"stats", nullptr, stats_sync, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"maxBatchFor", nullptr, max_batch_for_sync, nullptr, nullptr, nullptr, napi_default, nullptr},
-        {"base64Async", nullptr, base64_async, nullptr, nullptr, nullptr, napi_default, nullptr},
     };
     napi_define_properties(env, exports, sizeof(d) / sizeof(d[0]), d);
     return exports;
