@@ -58,7 +58,8 @@ static std::mutex g_strips_mu;       // guards every ire_engine::sessions list a
 
 namespace ire {
 
-constexpr int kSlots = 4;             // gathering | computing | two waiting for their polls
+constexpr int kSlots = 8;             // gathering | computing | up to six waiting for their polls (a caller that submits a burst before its first poll)
+constexpr int kSlotsEager = 3;        // staging allocated at the first job of a shape; the other slots get theirs when first needed
 constexpr int kLingerQuietUs = 250, kLingerMaxUs = 1500;
 
 struct BatchSlot {
@@ -151,7 +152,9 @@ static int slot_for(ire_engine* E, int h, int w) {
         if (S.h == h && S.w == w && (int)S.jobs.size() < mb) return *it;
     }
     int pick = -1;
-    for (int i = 0; i < kSlots; ++i) if (E->slots[i].state == BatchSlot::FREE) { pick = i; break; }
+    const size_t need = (size_t)h * w * 3 * (size_t)mb;
+    for (int i = 0; i < kSlots && pick < 0; ++i) if (E->slots[i].state == BatchSlot::FREE && E->slots[i].cap >= need) pick = i;     // one whose staging exists
+    for (int i = 0; i < kSlots && pick < 0; ++i) if (E->slots[i].state == BatchSlot::FREE) pick = i;
     if (pick < 0) {
         for (int i = 0; i < kSlots && pick < 0; ++i) {
             BatchSlot& S = E->slots[i];
@@ -623,9 +626,9 @@ int ire_submit(ire_engine* e, const uint8_t* rgb, int h, int w, int is_jpeg, con
                 (void)hipSetDevice(e->device);
                 if (!e->cs) IRE_HIP(hipStreamCreateWithFlags(&e->cs, hipStreamNonBlocking));
                 if (!e->os) IRE_HIP(hipStreamCreateWithFlags(&e->os, hipStreamNonBlocking));
-                // staging for every slot now, at this first shape (pinning 4 x 2 x max_batch images takes tens of ms): the
-                // first job pays it once, instead of three later jobs paying it one slot at a time in the middle of a stream
-                try { for (auto& S : e->slots) slot_reserve(S, ib * (size_t)e->eng->max_batch(), e->eng->max_batch()); }
+                // staging for the three slots of a steady stream now, at this first shape (pinning 3 x 2 x max_batch images takes tens
+                // of ms): the first job pays it once, instead of later jobs paying it one slot at a time in the middle of a stream
+                try { for (int i = 0; i < kSlotsEager; ++i) slot_reserve(e->slots[i], ib * (size_t)e->eng->max_batch(), e->eng->max_batch()); }
                 catch (...) { if (prev >= 0) (void)hipSetDevice(prev); throw; }
                 if (prev >= 0) (void)hipSetDevice(prev);
                 e->worker = std::thread(launcher_loop, e);
