@@ -32,7 +32,7 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 #ifndef C3_RES_PRE
-#define C3_RES_PRE 2
+#define C3_RES_PRE -1     // residual groups requested before the MFMAs: -1 = per width (C = 32: 2, C = 64: 1); >= 0 forces one value (build-time A/B)
 #endif
 #ifndef C3_SCALAR
 #define C3_SCALAR 1
@@ -388,7 +388,10 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
 
     f32x16_t acc[2][NTL];
     uint4 erv[2 * NTL][2];
-    constexpr int RES_PRE = C3_RES_PRE < 2 * NTL ? C3_RES_PRE : 2 * NTL;    // residual groups requested before the MFMAs; the rest after the k-loop
+    // residual groups requested before the MFMAs, the rest after the k-loop.  Same box, C = 64 with the line-coalesced epilogue: 0 / 1 / 2 / 3 / 4
+    // = 218.4 / 216.9 / 223.5 / 294.8 / 299.6 us (from 3 on the consumer spills into its k-loop); C = 32: 326.8 / 329.4 / 320.3
+    constexpr int RES_WANT = C3_RES_PRE >= 0 ? C3_RES_PRE : (C == 64 ? 1 : 2);
+    constexpr int RES_PRE = RES_WANT < 2 * NTL ? RES_WANT : 2 * NTL;
     unsigned eoffs[2];
     bool einb[2];
     // C = 32 line-coalesced epilogue (TEPI, off by default -- see C3_TEPI): the accumulator layout (lane = pixel) makes every lane
