@@ -44,14 +44,33 @@ __global__ void fusion_luma_kernel(const uint8_t* __restrict__ rgb, int k, int H
     const int v = i / (Hq * Wq), rem = i - v * Hq * Wq;
     const int yq = rem / Wq, xq = rem - yq * Wq;
     unsigned sum = 0;
-    for (int dy = 0; dy < 4; ++dy)
-        for (int dx = 0; dx < 4; ++dx) {
-            const size_t p = ((size_t)v * H + (yq * 4 + dy)) * W + xq * 4 + dx;
-            const uint8_t* px = rgb + p * 3;
-            const unsigned l = (77u * px[0] + 150u * px[1] + 29u * px[2] + 128u) >> 8;
-            L[p] = (uint8_t)l;
-            sum += l;
+    if ((reinterpret_cast<uintptr_t>(rgb) & 3u) == 0) {
+        // word-wide: a row of the block is 12 bytes = three aligned dwords (W % 8 == 0); a pixel's luma is ONE v_dot4_u32_u8 on
+        // the window that starts at its R byte (weights 77, 150, 29, 0; + 128), its value byte 1 of the result (< 2^16)
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy) {
+            const size_t p = ((size_t)v * H + (yq * 4 + dy)) * W + xq * 4;
+            const unsigned* src = reinterpret_cast<const unsigned*>(rgb + p * 3);
+            const unsigned d0 = src[0], d1 = src[1], d2 = src[2];
+            constexpr unsigned LW = 0x001d964du;
+            const unsigned l0 = __builtin_amdgcn_udot4(d0, LW, 128u, false);
+            const unsigned l1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), LW, 128u, false);
+            const unsigned l2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), LW, 128u, false);
+            const unsigned l3 = __builtin_amdgcn_udot4(d2 >> 8, LW, 128u, false);
+            const unsigned lw = __builtin_amdgcn_perm(l1, l0, 0x0c0c0501u) | __builtin_amdgcn_perm(l3, l2, 0x05010c0cu);   // bytes 1 of l0..l3
+            *reinterpret_cast<unsigned*>(L + p) = lw;
+            sum = __builtin_amdgcn_sad_u8(lw, 0u, sum);
         }
+    } else {
+        for (int dy = 0; dy < 4; ++dy)
+            for (int dx = 0; dx < 4; ++dx) {
+                const size_t p = ((size_t)v * H + (yq * 4 + dy)) * W + xq * 4 + dx;
+                const uint8_t* px = rgb + p * 3;
+                const unsigned l = (77u * px[0] + 150u * px[1] + 29u * px[2] + 128u) >> 8;
+                L[p] = (uint8_t)l;
+                sum += l;
+            }
+    }
     Q[((size_t)v * Hq + yq) * qp + xq] = (uint8_t)((sum + 8u) >> 4);
 }
 
@@ -92,8 +111,14 @@ __global__ __launch_bounds__(256) void fusion_sad_kernel(const uint8_t* __restri
                                                          unsigned* __restrict__ ticket) {
     using C = SadCfg<MODE>;
     constexpr int R = C::R, N = C::N, M = C::M, STEP = C::STEP, D = 2 * R + 1;
-    __shared__ unsigned s_ref[C::SR][C::TWD];
-    __shared__ unsigned s_view[C::VR][C::VWD];
+    // MODE 1 keeps only the SAMPLED pixels (every 2nd one): a reference dword = four samples = eight pixels, and the view's
+    // rows as two planes -- its even and its odd pixels, interleaved per dword pair -- because candidate dx reads the plane of
+    // dx's parity at a byte offset of (dx + 4) >> 1: one v_alignbyte and one v_sad_u8 per FOUR samples and candidate, no masks
+    // (the image's interior is a whole number of such dwords: (PW - 2 M) % 8 == 0).
+    constexpr int RWD = MODE == 0 ? C::TWD : C::TWD / 2;          // reference dwords per tile row
+    constexpr int VPR = C::VWD / 2;                                // MODE 1: dword pairs per view row
+    __shared__ __attribute__((aligned(16))) unsigned s_ref[C::SR][RWD];
+    __shared__ __attribute__((aligned(16))) unsigned s_view[C::VR][C::VWD];                     // MODE 1: [row][pair][even, odd]
     __shared__ unsigned s_sad[2][N];
     __shared__ int s_last;
     const int tid = threadIdx.x;
@@ -114,49 +139,121 @@ __global__ __launch_bounds__(256) void fusion_sad_kernel(const uint8_t* __restri
     const int tiles_x = (PW - 2 * M + C::TW - 1) / C::TW;
     const int tiles_y = ((PH - 2 * M + STEP - 1) / STEP + C::SR - 1) / C::SR;
     const int wave = tid >> 6, lane = tid & 63;
-    for (int tile = blockIdx.x; tile < tiles_x * tiles_y; tile += gridDim.x) {   // uniform per workgroup
+    // A tile's global loads are all issued together (one round trip), and the NEXT tile's before this tile's arithmetic.
+    constexpr int NRL = MODE == 0 ? C::ITEMS : C::SR * RWD / 256;
+    constexpr int NVL = MODE == 0 ? (C::VR * C::VWD + 255) / 256 : (C::VR * VPR + 255) / 256;
+    constexpr int LW = MODE == 0 ? 1 : 2;                          // dwords per staged item
+    unsigned tr[NRL][LW], tv[NVL][LW];
+    auto load_tile = [&](int tile) {
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int gy0 = M + ty * C::SR * STEP, gx0 = M + tx * C::TW;
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int it = 0; it < NRL; ++it) {
+                const int i = it * 256 + tid, r = i / C::TWD, j = i - r * C::TWD;
+                const int yy = min(gy0 + r * STEP, PH - 1), xd = min((gx0 >> 2) + j, pd - 1);
+                tr[it][0] = reinterpret_cast<const unsigned*>(P0 + (size_t)yy * pitch)[xd];
+            }
+#pragma unroll
+            for (int it = 0; it < NVL; ++it) {
+                const int i = min(it * 256 + tid, C::VR * C::VWD - 1), r = i / C::VWD, j = i - r * C::VWD;
+                const int yy = min(gy0 + by - R + r, PH - 1), xd = min(((gx0 + bx - 4) >> 2) + j, pd - 1);
+                tv[it][0] = reinterpret_cast<const unsigned*>(Pv + (size_t)yy * pitch)[xd];
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < NRL; ++it) {
+                const int i = it * 256 + tid, r = i / RWD, c = i - r * RWD;
+                const unsigned* src = reinterpret_cast<const unsigned*>(P0 + (size_t)min(gy0 + r * STEP, PH - 1) * pitch);
+                tr[it][0] = src[min((gx0 >> 2) + 2 * c, pd - 1)]; tr[it][LW - 1] = src[min((gx0 >> 2) + 2 * c + 1, pd - 1)];
+            }
+#pragma unroll
+            for (int it = 0; it < NVL; ++it) {
+                const int i = min(it * 256 + tid, C::VR * VPR - 1), r = i / VPR, c = i - r * VPR;
+                const unsigned* src = reinterpret_cast<const unsigned*>(Pv + (size_t)min(gy0 + by - R + r, PH - 1) * pitch);
+                const int x = ((gx0 + bx - 4) >> 2) + 2 * c;
+                tv[it][0] = src[min(x, pd - 1)]; tv[it][LW - 1] = src[min(x + 1, pd - 1)];
+            }
+        }
+    };
+    auto write_tile = [&]() {
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int it = 0; it < NRL; ++it) (&s_ref[0][0])[it * 256 + tid] = tr[it][0];
+#pragma unroll
+            for (int it = 0; it < NVL; ++it)
+                if (it * 256 + tid < C::VR * C::VWD) (&s_view[0][0])[it * 256 + tid] = tv[it][0];
+        } else {
+#pragma unroll
+            for (int it = 0; it < NRL; ++it)
+                (&s_ref[0][0])[it * 256 + tid] = __builtin_amdgcn_perm(tr[it][LW - 1], tr[it][0], 0x06040200u);      // pixels 0, 2, 4, 6 of the eight
+#pragma unroll
+            for (int it = 0; it < NVL; ++it)
+                if (it * 256 + tid < C::VR * VPR)
+                    reinterpret_cast<uint2*>(&s_view[0][0])[it * 256 + tid] =
+                        make_uint2(__builtin_amdgcn_perm(tv[it][LW - 1], tv[it][0], 0x06040200u),
+                                   __builtin_amdgcn_perm(tv[it][LW - 1], tv[it][0], 0x07050301u));
+        }
+    };
+    const int ntiles = tiles_x * tiles_y;
+    if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {   // uniform per workgroup
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         const int gy0 = M + ty * C::SR * STEP, gx0 = M + tx * C::TW;
         __syncthreads();   // the previous tile's readers are done (and s_sad is zero on the first pass)
-#pragma unroll
-        for (int it = 0; it < C::ITEMS; ++it) {
-            const int i = it * 256 + tid, r = i / C::TWD, j = i - r * C::TWD;
-            const int yy = min(gy0 + r * STEP, PH - 1), xd = min((gx0 >> 2) + j, pd - 1);
-            s_ref[r][j] = reinterpret_cast<const unsigned*>(P0 + (size_t)yy * pitch)[xd];
-        }
-        for (int i = tid; i < C::VR * C::VWD; i += 256) {
-            const int r = i / C::VWD, j = i - r * C::VWD;
-            const int yy = min(gy0 + by - R + r, PH - 1), xd = min(((gx0 + bx - 4) >> 2) + j, pd - 1);
-            s_view[r][j] = reinterpret_cast<const unsigned*>(Pv + (size_t)yy * pitch)[xd];
-        }
+        write_tile();
+        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
         __syncthreads();
-        // The four waves split the candidate ROWS; a wave sweeps the tile once per row with its D accumulators.  (All N
-        // accumulators per thread in one unrolled pass is 4400 instructions executed once, one wave per SIMD: 35 us per
-        // launch against 12-18 us for this form, profiles/r02_experiments.md.)
+        // The four waves split the candidate ROWS; a wave sweeps the tile once per row with its D accumulators, in a LOOP.
+        // Straight-line code is what these short kernels cannot afford -- every instruction is fetched cold, once: all N
+        // accumulators per thread with the items unrolled (4400 instructions) took 35 us per launch (r02), all N accumulators
+        // kept across the tiles with only the candidates unrolled (~2000 instructions with the final reduction) 26.5 / 22.8 us
+        // (coarse / fine, one set) against 12.4 / 16.4 us for this form (profiles/r03_experiments.md).
 #pragma unroll 1
         for (int dy = -R + wave; dy <= R; dy += 4) {
             unsigned acc[D];
 #pragma unroll
             for (int c = 0; c < D; ++c) acc[c] = 0u;
+            if constexpr (MODE == 0) {
 #pragma unroll 2
-            for (int i = lane; i < C::SR * C::TWD; i += 64) {
-                const int r = i / C::TWD, j = i - r * C::TWD;
-                const int y = gy0 + r * STEP, x = gx0 + 4 * j;
-                unsigned mask = 0;
-                if (y < PH - M) {
+                for (int i = lane; i < C::SR * C::TWD; i += 64) {
+                    const int r = i / C::TWD, j = i - r * C::TWD;
+                    const int y = gy0 + r * STEP, x = gx0 + 4 * j;
+                    if (y >= PH - M || x >= PW - M) continue;
+                    unsigned mask = 0xffffffffu;
+                    if (x + 3 >= PW - M) {                   // the interior's last dword may be partial
+                        mask = 0;
 #pragma unroll
-                    for (int b = 0; b < 4; b += STEP)
-                        if (x + b < PW - M) mask |= 0xffu << (8 * b);
+                        for (int b = 0; b < 4; ++b)
+                            if (x + b < PW - M) mask |= 0xffu << (8 * b);
+                    }
+                    const unsigned a = s_ref[r][j] & mask;
+                    const unsigned* row = &s_view[r * STEP + dy + R][j];
+                    const unsigned w0 = row[0], w1 = row[1], w2 = row[2];
+#pragma unroll
+                    for (int dx = -R; dx <= R; ++dx) {
+                        const int o = dx + 4;   // byte offset of the window from dword j
+                        const unsigned win = o < 4 ? __builtin_amdgcn_alignbyte(w1, w0, o & 3)
+                                           : o < 8 ? __builtin_amdgcn_alignbyte(w2, w1, o & 3) : w2;
+                        acc[dx + R] = __builtin_amdgcn_sad_u8(a, win & mask, acc[dx + R]);
+                    }
                 }
-                const unsigned a = s_ref[r][j] & mask;
-                const unsigned* row = &s_view[r * STEP + dy + R][j];
-                const unsigned w0 = row[0], w1 = row[1], w2 = row[2];
+            } else {
+                const int nr = min(C::SR, (PH - M - gy0 + 1) >> 1), nc = min(RWD, (PW - M - gx0) >> 3);
+#pragma unroll 2
+                for (int i = lane; i < C::SR * RWD; i += 64) {
+                    const int r = i / RWD, c = i - r * RWD;
+                    if (r >= nr || c >= nc) continue;
+                    const unsigned a = s_ref[r][c];
+                    const uint2 p0 = *reinterpret_cast<const uint2*>(&s_view[r * STEP + dy + R][2 * c]);
+                    const uint2 p1 = *reinterpret_cast<const uint2*>(&s_view[r * STEP + dy + R][2 * c + 2]);
 #pragma unroll
-                for (int dx = -R; dx <= R; ++dx) {
-                    const int o = dx + 4;   // byte offset of the window from dword j
-                    const unsigned win = o < 4 ? __builtin_amdgcn_alignbyte(w1, w0, o & 3)
-                                       : o < 8 ? __builtin_amdgcn_alignbyte(w2, w1, o & 3) : w2;
-                    acc[dx + R] = __builtin_amdgcn_sad_u8(a, win & mask, acc[dx + R]);
+                    for (int dx = -R; dx <= R; ++dx) {
+                        const int o = (dx + 4) >> 1;         // sample t of the dword is byte o + t of the plane of dx's parity
+                        const unsigned lo = (dx & 1) ? p0.y : p0.x, hi = (dx & 1) ? p1.y : p1.x;
+                        const unsigned win = o == 0 ? lo : __builtin_amdgcn_alignbyte(hi, lo, o);
+                        acc[dx + R] = __builtin_amdgcn_sad_u8(a, win, acc[dx + R]);
+                    }
                 }
             }
 #pragma unroll
@@ -183,17 +280,24 @@ __global__ __launch_bounds__(256) void fusion_sad_kernel(const uint8_t* __restri
     for (int i = tid; i < 2 * N; i += 256) (&s_sad[0][0])[i] = 0;
     __syncthreads();
     const int total = (k - 1) * G * N;
-    for (int base = 0; base < total; base += 256 * 8) {    // eight loads in flight per thread (one round trip each otherwise);
-        unsigned t[8];                                     // LDS atomics on N addresses per view
+    // FL loads in flight per thread (one round trip each otherwise); the view / candidate of element i = (vv G + g) N + c are
+    // stepped, not divided out (i advances by 256: c by 256 % N): this code runs once, cold -- every instruction counts.
+    constexpr int FL = 16;
+    const int GN = G * N;
+    int ci = tid % N, i0 = tid;
+    for (int base = 0; base < total; base += 256 * FL) {
+        unsigned t[FL];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < FL; ++u) {
             const int i = base + u * 256 + tid;
             t[u] = i < total ? __hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = base + u * 256 + tid;
-            if (i < total) atomicAdd(&s_sad[i / (G * N)][i % N], t[u]);
+        for (int u = 0; u < FL; ++u) {
+            if (i0 < total) atomicAdd(&s_sad[i0 >= GN ? 1 : 0][ci], t[u]);     // LDS atomics on N addresses per view
+            i0 += 256;
+            ci += 256 % N;
+            ci -= ci >= N ? N : 0;
         }
     }
     __syncthreads();
@@ -230,38 +334,95 @@ __global__ __launch_bounds__(256) void fusion_sad_kernel(const uint8_t* __restri
     }
 }
 
-struct FuseWlut { unsigned w[256]; };   // the blend weights ride in the kernel arguments: no host-to-device copy
+struct FuseWlut { unsigned w[256]; };
+__device__ __forceinline__ unsigned cls_pack_bytes(unsigned a, unsigned b, unsigned c, unsigned d) { return a | (b << 8) | (c << 16) | (d << 24); }   // the blend weights ride in the kernel arguments: no host-to-device copy
 
-__global__ __launch_bounds__(256) void fusion_blend_kernel(const uint8_t* __restrict__ rgb, int k, int H, int W,
+// Rounded weighted mean of one byte position of the k views (the blend line of the header), word-wide caller below.
+// The division: n = num + (den >> 1) < 2^20 and den <= 3 * 1024, so the true quotient's fraction is a multiple of 1 / den and
+// (n + 0.5) / den sits at least 0.5 / 3072 = 1.6e-4 away from every integer, while v_rcp_f32 (1 ulp) and one rounded multiply
+// are off by at most 255.5 * 1.8e-7 = 4.6e-5: the truncated float product IS floor(n / den), no fix-up (tests/test_host_logic.py
+// walks every den with the reciprocal pushed 2 ulp either way).
+template <int K>
+__device__ __forceinline__ unsigned fuse_byte(const unsigned* __restrict__ s_w, unsigned w0, unsigned a, unsigned b, unsigned d) {
+    unsigned num, den;
+    if constexpr (K == 2) {
+        const unsigned m = (a + b + 1u) >> 1;
+        const unsigned wa = s_w[__builtin_amdgcn_sad_u8(a, m, 0u)], wb = s_w[__builtin_amdgcn_sad_u8(b, m, 0u)];
+        num = __umul24(wa, a) + __umul24(wb, b); den = wa + wb;
+    } else {
+        // the weighted sum does not care which view a value came from: sorted, the median's own weight is WLUT[0] (read once per
+        // thread), so two table reads per byte, and the two distances are plain differences
+        const unsigned lo = min(min(a, b), d), hi = max(max(a, b), d), m = max(min(a, b), min(max(a, b), d));      // v_min3 / v_max3 / v_med3
+        const unsigned wl = s_w[m - lo], wh = s_w[hi - m];
+        num = __umul24(wl, lo) + __umul24(wh, hi) + __umul24(w0, m); den = wl + wh + w0;
+    }
+    const float nf = (float)(num + (den >> 1)) + 0.5f;
+    return (unsigned)(nf * __builtin_amdgcn_rcpf((float)den));
+}
+
+// A thread blends FOUR pixels = 12 bytes = three dwords of the output row (W % 8 == 0: a row is a whole number of groups and
+// its byte pitch a multiple of 4).  A view's 12 source bytes start at ((v H + y + dy) W + x + dx) * 3 -- any alignment, but the
+// SAME one for every group of a view (W * 3 % 4 == 0), so they are four aligned dwords and three v_alignbyte by a per-view
+// uniform amount.  The blend itself does not care which channel a byte is: twelve independent bytes.  Groups that touch the
+// left / right edge under their shift (replicate clamp per PIXEL) gather their bytes one by one.
+template <int K>
+__global__ __launch_bounds__(256) void fusion_blend_kernel(const uint8_t* __restrict__ rgb, int H, int W,
                                                            const int* __restrict__ shifts,
                                                            const FuseWlut wlut, const unsigned* __restrict__ wluts, uint8_t* __restrict__ out) {
     __shared__ unsigned s_w[256];
     const size_t set = blockIdx.y;                       // view set of a batched call; its blend table comes from `wluts` (one call: kernel arguments)
     s_w[threadIdx.x] = wluts ? wluts[set * 256 + threadIdx.x] : wlut.w[threadIdx.x];
-    rgb += set * (size_t)k * H * W * 3; out += set * (size_t)H * W * 3; shifts += set * 6;
+    rgb += set * (size_t)K * H * W * 3; out += set * (size_t)H * W * 3; shifts += set * 6;
     __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= H * W) return;
-    const int y = i / W, x = i - y * W;
-    const uint8_t* p[3];
-    for (int v = 0; v < k; ++v) {
-        const int yy = min(max(y + shifts[v * 2], 0), H - 1), xx = min(max(x + shifts[v * 2 + 1], 0), W - 1);
-        p[v] = rgb + (((size_t)v * H + yy) * W + xx) * 3;
-    }
-    for (int c = 0; c < 3; ++c) {
-        int a = p[0][c], b = p[1][c], m;
-        unsigned num, den;
-        if (k == 2) {
-            m = (a + b + 1) >> 1;
-            const unsigned wa = s_w[abs(a - m)], wb = s_w[abs(b - m)];
-            num = wa * a + wb * b; den = wa + wb;
+    const int gpr = W >> 2;
+    const int gi = blockIdx.x * 256 + threadIdx.x;
+    if (gi >= H * gpr) return;
+    const int y = gi / gpr, x0 = (gi - y * gpr) * 4;
+    unsigned e[3][3];
+#pragma unroll
+    for (int v = 0; v < K; ++v) {
+        const int sy = shifts[v * 2], sx = shifts[v * 2 + 1];
+        const int yy = min(max(y + sy, 0), H - 1);
+        const uint8_t* row = rgb + ((size_t)v * H + yy) * W * 3;
+        if (x0 + sx >= 0 && x0 + sx + 3 <= W - 1) {
+            const uint8_t* p = row + (x0 + sx) * 3;
+            const unsigned rem = (unsigned)(reinterpret_cast<uintptr_t>(p) & 3u);
+            const unsigned* q = reinterpret_cast<const unsigned*>(p - rem);
+            const unsigned d0 = q[0], d1 = q[1], d2 = q[2], d3 = rem ? q[3] : 0u;     // rem == 0: the 12 bytes end with d2
+            e[v][0] = __builtin_amdgcn_alignbyte(d1, d0, rem);
+            e[v][1] = __builtin_amdgcn_alignbyte(d2, d1, rem);
+            e[v][2] = __builtin_amdgcn_alignbyte(d3, d2, rem);
         } else {
-            const int d = p[2][c];
-            m = max(min(a, b), min(max(a, b), d));
-            const unsigned wa = s_w[abs(a - m)], wb = s_w[abs(b - m)], wd = s_w[abs(d - m)];
-            num = wa * a + wb * b + wd * d; den = wa + wb + wd;
+            unsigned char t[12];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint8_t* p = row + min(max(x0 + i + sx, 0), W - 1) * 3;
+                t[3 * i] = p[0]; t[3 * i + 1] = p[1]; t[3 * i + 2] = p[2];
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) e[v][j] = cls_pack_bytes(t[4 * j], t[4 * j + 1], t[4 * j + 2], t[4 * j + 3]);
         }
-        out[(size_t)i * 3 + c] = (uint8_t)((num + (den >> 1)) / den);
+    }
+    unsigned o[3];
+    const unsigned w0 = s_w[0];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        unsigned r = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const unsigned a = (e[0][j] >> (8 * t)) & 0xffu, b = (e[1][j] >> (8 * t)) & 0xffu;
+            const unsigned d = K == 3 ? (e[2][j] >> (8 * t)) & 0xffu : 0u;
+            r |= fuse_byte<K>(s_w, w0, a, b, d) << (8 * t);
+        }
+        o[j] = r;
+    }
+    uint8_t* po = out + ((size_t)y * W + x0) * 3;
+    if ((reinterpret_cast<uintptr_t>(po) & 3u) == 0) {
+        unsigned* pw = reinterpret_cast<unsigned*>(po);
+        pw[0] = o[0]; pw[1] = o[1]; pw[2] = o[2];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) po[j] = (uint8_t)(o[j >> 2] >> (8 * (j & 3)));
     }
 }
 
@@ -319,13 +480,20 @@ void Engine::fuse_launch(const uint8_t* d_views, int nsets, int k, int h, int w,
     auto tiles = [](int ph, int pw, int m, int step, int tw, int sr) {
         return ceil_div(pw - 2 * m, tw) * ceil_div(ceil_div(ph - 2 * m, step), sr);
     };
-    const int g0 = std::min(FUSE_SAD_GRID, tiles(hq, wq, CR, 1, SadCfg<0>::TW, SadCfg<0>::SR));
-    const int g1 = std::min(FUSE_SAD_GRID, tiles(h, w, FM, 2, SadCfg<1>::TW, SadCfg<1>::SR));
+    // Workgroups per view and set: a lone set spreads its tiles over the chip (one tile per workgroup at 1024^2); a batch keeps
+    // ~2 workgroups per CU in total and walks several tiles each (the next tile's loads fly under this tile's arithmetic), which
+    // also shortens the last workgroup's row sum.  Same box, 8 sets x 3 views at 1024^2, coarse / fine: 62 / 124 workgroups per
+    // view 22.3 / 36.0 us, 32 / 32: 17.2 / 22.9 us, 16 / 16: 19.9 / 31.7 us (tools/r03_fus2.sh).
+    static const int gcap_env = getenv("IRE_FUSE_GCAP") ? atoi(getenv("IRE_FUSE_GCAP")) : 0;
+    const int gcap = gcap_env > 0 ? gcap_env : std::max(32, 512 / ((k - 1) * nsets));
+    const int g0 = std::min(std::min(FUSE_SAD_GRID, gcap), tiles(hq, wq, CR, 1, SadCfg<0>::TW, SadCfg<0>::SR));
+    const int g1 = std::min(std::min(FUSE_SAD_GRID, gcap), tiles(h, w, FM, 2, SadCfg<1>::TW, SadCfg<1>::SR));
     hipLaunchKernelGGL(fusion_sad_kernel<0>, dim3(g0, k - 1, nsets), dim3(256), 0, s, d_fQ_, k, hq, wq, qp, d_coarse, d_sh, (int*)nullptr,
                        d_fsad_, d_ticket);
     hipLaunchKernelGGL(fusion_sad_kernel<1>, dim3(g1, k - 1, nsets), dim3(256), 0, s, d_fL_, k, h, w, w, d_coarse, d_sh, (int*)d_shifts,
                        d_fsad_, d_ticket);
-    hipLaunchKernelGGL(fusion_blend_kernel, dim3(ceil_div((int)px, 256), nsets), dim3(256), 0, s, d_views, k, h, w, d_sh, lut, d_wluts, d_out);
+    if (k == 3) hipLaunchKernelGGL(fusion_blend_kernel<3>, dim3(ceil_div((int)(px / 4), 256), nsets), dim3(256), 0, s, d_views, h, w, d_sh, lut, d_wluts, d_out);
+    else hipLaunchKernelGGL(fusion_blend_kernel<2>, dim3(ceil_div((int)(px / 4), 256), nsets), dim3(256), 0, s, d_views, h, w, d_sh, lut, d_wluts, d_out);
     IRE_HIP(hipGetLastError());
     prof_end(s);
 }

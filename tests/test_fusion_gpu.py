@@ -101,3 +101,39 @@ def test_fusion_full_size(engine):
     out, sh = engine.fuse(views, noise_score=0.25)
     ref, rsh = ofu.fuse(views, 0.25)
     assert np.array_equal(sh, rsh) and np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("k", [2, 3])
+def test_blend_uncorrelated_views_every_weight_mix(engine, k):
+    """Views that share nothing: every byte difference 0..255 occurs, so the blend's weights run from 1 to 1024 in every mix and
+    its float-reciprocal division (fusion.hip fuse_byte) is exercised over its whole range of denominators."""
+    rng = np.random.default_rng(77 + k)
+    views = rng.integers(0, 256, (k, 192, 264, 3), dtype=np.uint8)
+    views[:, :64] = (views[:, :64].astype(int) // 64 * 64 + rng.integers(0, 3, views[:, :64].shape)).astype(np.uint8)   # near-equal bytes too
+    for noise in (0.0, 0.13, 0.5, 1.0):
+        out, sh = engine.fuse(views, noise_score=noise)
+        ref, rsh = ofu.fuse(views, noise)
+        assert np.array_equal(sh, rsh), (sh, rsh)
+        assert np.array_equal(out, ref), int(np.abs(out.astype(int) - ref.astype(int)).max())
+
+
+def test_device_pointers_of_any_alignment(engine):
+    """ire_fuse_device takes plain device pointers: views and result at byte offsets 1 / 3 / 2 of their allocations (the blend
+    realigns its dword loads per view and falls back to byte stores for a result that is not dword-aligned)."""
+    import ctypes
+    import torch
+    views = synth.fusion_views(96, 136, shifts=((0, 0), (6, -11), (-5, 14)), seed=5)
+    ref, rsh = ofu.fuse(views, 0.3)
+    n = views.size
+    for off_in, off_out in ((1, 0), (3, 2), (0, 1)):
+        buf = torch.zeros(n + 8, dtype=torch.uint8, device="cuda")
+        buf[off_in:off_in + n] = torch.from_numpy(views).cuda().reshape(-1)
+        obuf = torch.zeros(ref.size + 8, dtype=torch.uint8, device="cuda")
+        shifts = torch.zeros((3, 2), dtype=torch.int32, device="cuda")
+        engine._check(engine._lib.ire_fuse_device(engine._h, ctypes.c_void_p(buf.data_ptr() + off_in), 3, 96, 136, 0.3,
+                                                  ctypes.c_void_p(obuf.data_ptr() + off_out), ctypes.c_void_p(shifts.data_ptr()),
+                                                  engine._stream_ptr(None)))
+        torch.cuda.synchronize()
+        got = obuf[off_out:off_out + ref.size].cpu().numpy().reshape(ref.shape)
+        assert np.array_equal(shifts.cpu().numpy(), rsh) and np.array_equal(got, ref), (off_in, off_out)
+        assert int(obuf[:off_out].sum()) == 0 and int(obuf[off_out + ref.size:].sum()) == 0      # nothing written outside

@@ -187,3 +187,23 @@ def test_queue_backoff_policy():
     assert retry.calculate_backoff(3, 1000, 0.3, rng=lambda: 1.0) == 5200
     assert retry.calculate_backoff(0, 1000, 0.3, rng=lambda: 0.5) == 1000      # exponent clamps at 0
     assert retry.QUEUE_DEFAULTS["name"] == "image-restoration-jobs" and retry.QUEUE_DEFAULTS["attempts"] == 5
+
+
+def test_blend_division_by_float_reciprocal_is_exact():
+    import numpy as np
+    """fusion.hip fuse_byte: floor((num + den // 2) / den) as trunc((n + 0.5) * rcp(den)) in float32, for every denominator the
+    blend can form (2 .. 3 * 1024) at the numerators closest to an integer quotient (remainder 0 and den - 1, every quotient
+    0..255), with the reciprocal pushed up to 2 ulp either way (v_rcp_f32 is specified to 1 ulp)."""
+    den = np.arange(2, 3 * 1024 + 1, dtype=np.int64)[:, None, None]
+    q = np.arange(0, 256, dtype=np.int64)[None, :, None]
+    rem = np.stack([np.zeros_like(den[:, 0, 0]), den[:, 0, 0] - 1], axis=1)[:, None, :]
+    n = q * den + rem                                                # [den][q][2]
+    n = np.minimum(n, 255 * den + den // 2)                          # the blend's largest numerator
+    want = n // den
+    nf = n.astype(np.float32) + np.float32(0.5)
+    assert np.array_equal(nf.astype(np.float64), n + 0.5)            # exact in float32
+    r = (np.float32(1.0) / den.astype(np.float32)).astype(np.float32)
+    for ulps in (-2, -1, 0, 1, 2):
+        rr = (r.view(np.int32) + ulps).view(np.float32)
+        got = (nf * rr).astype(np.float32).astype(np.int64)
+        assert np.array_equal(got, want), ulps
