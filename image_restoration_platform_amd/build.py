@@ -47,6 +47,9 @@ SOURCES = [
 # IRE_SLP=1 builds with the vectorizer on (A/B).
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-D__HIP_PLATFORM_AMD__"] + ([] if os.environ.get("IRE_SLP") == "1" else ["-fno-slp-vectorize"]) + \
+         (["-DIRE_ST_LINE=" + os.environ["IRE_ST_LINE"]] if os.environ.get("IRE_ST_LINE") else []) + \
+         (["-DIRE_ST_PART=" + os.environ["IRE_ST_PART"]] if os.environ.get("IRE_ST_PART") else []) + \
+         (["-DIRE_LD_ONCE=" + os.environ["IRE_LD_ONCE"]] if os.environ.get("IRE_LD_ONCE") else []) + \
          os.environ.get("IRE_XFLAGS", "").split()          # extra compiler flags for build-time A/B (tools/s2_xflags.sh)
 
 def _hipcc():

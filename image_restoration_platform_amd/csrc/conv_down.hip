@@ -232,7 +232,7 @@ __global__ __launch_bounds__(DN_THREADS) void conv_down_kernel(ConvArgs a) {
                     }
                     sA += inb[m] ? ts : 0.f; qA += inb[m] ? tq : 0.f;
                     const u32x4_t wv4 = {w[0], w[1], w[2], w[3]};
-                    __builtin_amdgcn_raw_buffer_store_b128(wv4, orsrc, inb[m] ? offs[m] + (unsigned)(j * 64 + pp * 32) : 0xffffffffu, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(wv4, orsrc, inb[m] ? offs[m] + (unsigned)(j * 64 + pp * 32) : 0xffffffffu, 0, IRE_ST_PART);
                 }
                 // sum over the 32 lanes of each half (one 16-B chunk each): cout >= 64 => a chunk never splits into two groups
                 sA = dn_ror_add<1>(sA); qA = dn_ror_add<1>(qA);

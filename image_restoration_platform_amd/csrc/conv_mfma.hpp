@@ -2,6 +2,27 @@
 #pragma once
 #include "common.hpp"
 
+// Cache policy of the activation stores (raw_buffer_store aux: 1 = sc0, 2 = nt, 16 = sc1).  IRE_ST_LINE: the line-coalesced
+// epilogues (a wave-instruction = whole 128-B lines) write THROUGH (sc1): the XCD's L2 keeps no dirty copy, so the kernel
+// boundary has nothing to write back and the L2 stays with the input halos and weights -- same box, plain -> sc1: conv_pc<64>
+// RB2 211.8 / 216.8 -> 196.8 / 196.3 us, RB1 172 -> 164 / 165.5, conv_w4 168.2 / 155.0 -> 165.6 / 152.0.  IRE_ST_PART: epilogues
+// whose store instruction covers PARTS of lines (32 B per lane from the accumulator layout, 64 B of a 128-B pixel row) stay
+// write-back -- written through, every part is its own memory write: conv_pc<32> 311 -> 449 us, conv_down 157 -> 201
+// (profiles/r03_experiments.md).  Build-time A/B: IRE_ST_LINE=..., IRE_ST_PART=...
+#ifndef IRE_ST_LINE
+#define IRE_ST_LINE 16
+#endif
+// IRE_LD_ONCE: loads of bytes a kernel reads exactly once AS WHOLE LINES (conv_pc<64>'s residual rows, conv_up's level-0 skip rows)
+// are non-temporal (nt): same box, conv_up<2> 299.4 / 296.1 -> 286.4 / 289.4 us, conv_pc<64> RB2 195.4 / 195.9 -> 191.9 / 191.9.
+// Not where a line is read in two halves at different times (conv_up<4>, <8>: 64-B pieces of 128-B rows: 246 -> 267 us, 219 -> 234),
+// and no effect on conv_w4's and conv_pc<32>'s residual loads.
+#ifndef IRE_LD_ONCE
+#define IRE_LD_ONCE 2
+#endif
+#ifndef IRE_ST_PART
+#define IRE_ST_PART 0
+#endif
+
 namespace ire {
 
 enum { PRO_NONE = 0, PRO_GN = 1, PRO_U8 = 2 };

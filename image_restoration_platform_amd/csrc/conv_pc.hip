@@ -465,7 +465,7 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         const bool ok = trow[m] && tcol + 16 * k < a.Wout;
-                        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ok ? toffs[m] + (unsigned)(16 * k * 2 * C) : 0xffffffffu, 0, 0);
+                        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ok ? toffs[m] + (unsigned)(16 * k * 2 * C) : 0xffffffffu, 0, IRE_LD_ONCE);
                         erv[k][m] = make_uint4(v.x, v.y, v.z, v.w);
                     }
             } else if constexpr (RESID && (C3_ABL & 64)) {
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
                     sA = __builtin_fmaf(ts0, mf, sA); qA = __builtin_fmaf(tq0, mf, qA);
                     const u32x4_t o4 = {w[0], w[1], w[2], w[3]};
                     if constexpr (C3_ABL & 16) asm volatile("" :: "v"(o4));
-                    else __builtin_amdgcn_raw_buffer_store_b128(o4, orsrc, ok ? toffs[m] + (unsigned)(8 * k * 2 * C) : 0xffffffffu, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(o4, orsrc, ok ? toffs[m] + (unsigned)(8 * k * 2 * C) : 0xffffffffu, 0, IRE_ST_LINE);
                 }
             }
             if constexpr (!(C3_ABL & 32)) {
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
                     sB = __builtin_fmaf(ts1, mf, sB); qB = __builtin_fmaf(tq1, mf, qB);
                     const u32x4_t o4 = {w[0], w[1], w[2], w[3]};
                     if constexpr (C3_ABL & 16) asm volatile("" :: "v"(o4));
-                    else __builtin_amdgcn_raw_buffer_store_b128(o4, orsrc, ok ? toffs[m] + (unsigned)(16 * k * 2 * C) : 0xffffffffu, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(o4, orsrc, ok ? toffs[m] + (unsigned)(16 * k * 2 * C) : 0xffffffffu, 0, IRE_ST_LINE);
                 }
             }
             if constexpr (!(C3_ABL & 32)) {
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
                     if constexpr (C == 32) { sB = __builtin_fmaf(ts1, mf[m], sB); qB = __builtin_fmaf(tq1, mf[m], qB); }
                     const u32x4_t wv4 = {w[0], w[1], w[2], w[3]};
                     if constexpr (C3_ABL & 16) asm volatile("" :: "v"(wv4));
-                    else __builtin_amdgcn_raw_buffer_store_b128(wv4, orsrc, einb[m] ? eoffs[m] + (unsigned)(g * 32) : 0xffffffffu, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(wv4, orsrc, einb[m] ? eoffs[m] + (unsigned)(g * 32) : 0xffffffffu, 0, IRE_ST_PART);
                 }
                 if constexpr (C == 32) { vs[2 * pp] = sA; vq[2 * pp] = qA; vs[2 * pp + 1] = sB; vq[2 * pp + 1] = qB; }
                 else { vs[g] = sA; vq[g] = qA; }

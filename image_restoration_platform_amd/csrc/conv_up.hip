@@ -222,7 +222,7 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
                         unsigned w[4] = {up_pack(c[8 * pp + 0], c[8 * pp + 1]), up_pack(c[8 * pp + 2], c[8 * pp + 3]),
                                          up_pack(c[8 * pp + 4], c[8 * pp + 5]), up_pack(c[8 * pp + 6], c[8 * pp + 7])};
                         const u32x4_t wv4 = {w[0], w[1], w[2], w[3]};
-                        if constexpr (!(IRE_UP_ABL & 4)) __builtin_amdgcn_raw_buffer_store_b128(wv4, orsrc, inb[m] ? off + (unsigned)(pp * 32) : 0xffffffffu, 0, 0);
+                        if constexpr (!(IRE_UP_ABL & 4)) __builtin_amdgcn_raw_buffer_store_b128(wv4, orsrc, inb[m] ? off + (unsigned)(pp * 32) : 0xffffffffu, 0, IRE_ST_PART);
                         else asm volatile("" :: "v"(wv4));
                         if constexpr (!(IRE_UP_ABL & 2))
 #pragma unroll
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
                 for (int pp = 0; pp < 2; ++pp) {
                     const u32x4_t wv4 = {up_pack(c[8 * pp + 0], c[8 * pp + 1]), up_pack(c[8 * pp + 2], c[8 * pp + 3]),
                                          up_pack(c[8 * pp + 4], c[8 * pp + 5]), up_pack(c[8 * pp + 6], c[8 * pp + 7])};
-                    __builtin_amdgcn_raw_buffer_store_b128(wv4, orsrc, inb ? off + (unsigned)(pp * 32) : 0xffffffffu, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(wv4, orsrc, inb ? off + (unsigned)(pp * 32) : 0xffffffffu, 0, IRE_ST_PART);
                 }
             }
         }
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
         for (int i = 0; i < 4; ++i) {
             const int p = lp0 + i * 16;
             const bool ok = rowok && ox0 + p < a.Wout;
-            skpre[i] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, ok ? (unsigned)((((2 * ly) * a.Wout + ox0 + p) * C + lc * 8) * 2) : 0xffffffffu, 0, 0);
+            skpre[i] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, ok ? (unsigned)((((2 * ly) * a.Wout + ox0 + p) * C + lc * 8) * 2) : 0xffffffffu, 0, C == 32 ? IRE_LD_ONCE : 0);
         }
     };
     auto epilogue_t = [&](const UpItem& it) __attribute__((always_inline)) {
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
             for (int i = 0; i < CPP; ++i) {
                 const int p = lp0 + i * PSTEP;
                 const bool ok = rowok && ox0 + p < a.Wout;
-                sk[i] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, ok ? (unsigned)(((oy * a.Wout + ox0 + p) * C + pc * PCH + lc * 8) * 2) : 0xffffffffu, 0, 0);
+                sk[i] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, ok ? (unsigned)(((oy * a.Wout + ox0 + p) * C + pc * PCH + lc * 8) * 2) : 0xffffffffu, 0, C == 32 ? IRE_LD_ONCE : 0);
             }
         };
         if constexpr (!(IRE_UP_ABL & 1)) {
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(UP_THREADS) void conv_up_kernel(ConvArgs a) {
                     ssum[d >> 1] = __builtin_amdgcn_fdot2_f32_bf16(bv, ones, ssum[d >> 1], false);
                     qsum[d >> 1] = __builtin_amdgcn_fdot2_f32_bf16(bv, bv, qsum[d >> 1], false);
                 }
-                if constexpr (!(IRE_UP_ABL & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ok ? (unsigned)(((oy * a.Wout + ox0 + p) * C + it.nb * UP_NT + scq * 8) * 2) : 0xffffffffu, 0, 0);
+                if constexpr (!(IRE_UP_ABL & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ok ? (unsigned)(((oy * a.Wout + ox0 + p) * C + it.nb * UP_NT + scq * 8) * 2) : 0xffffffffu, 0, (C == 32 ? IRE_ST_LINE : IRE_ST_PART));
                 else asm volatile("" :: "v"(v));
             }
         }

@@ -536,7 +536,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
                 if constexpr (WAVES == 8) {
                     // range-checked buffer store: out-of-image lanes get an offset past num_records and are dropped by the hardware
                     const u32x4_t wv4 = {w[0], w[1], w[2], w[3]};
-                    __builtin_amdgcn_raw_buffer_store_b128(wv4, orsrc, st_ok ? offs[m] + (unsigned)(j * 64 + pp * 32) : 0xffffffffu, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(wv4, orsrc, st_ok ? offs[m] + (unsigned)(j * 64 + pp * 32) : 0xffffffffu, 0, IRE_ST_PART);
                 } else {          // 512-register form: no room for the resource descriptor's live range
                     if (st_ok) *reinterpret_cast<uint4*>(obase + offs[m] + (unsigned)(j * 64 + pp * 32)) = make_uint4(w[0], w[1], w[2], w[3]);
                 }
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
                     const bool ok = trow[m] && tcol0 + 16 * q + PPR * k < a.Wout && (!(DBG & 4) || w[0] == 0x12345678u);
                     ssum += ok ? s1 : 0.f; qsum += ok ? q1 : 0.f;
                     const u32x4_t o4 = {w[0], w[1], w[2], w[3]};
-                    __builtin_amdgcn_raw_buffer_store_b128(o4, orsrc, ok ? toffs[m] + (unsigned)(NRD * q + k) * cstep : 0xffffffffu, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o4, orsrc, ok ? toffs[m] + (unsigned)(NRD * q + k) * cstep : 0xffffffffu, 0, IRE_ST_LINE);
                 }
                 if constexpr (RESID) { if (2 * m + q + 3 < 2 * C::MT) load_resid_pass(2 * m + q + 3, rvt[(2 * m + q) % 3]); }
             }
