@@ -50,6 +50,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-
          (["-DIRE_ST_LINE=" + os.environ["IRE_ST_LINE"]] if os.environ.get("IRE_ST_LINE") else []) + \
          (["-DIRE_ST_PART=" + os.environ["IRE_ST_PART"]] if os.environ.get("IRE_ST_PART") else []) + \
          (["-DIRE_LD_ONCE=" + os.environ["IRE_LD_ONCE"]] if os.environ.get("IRE_LD_ONCE") else []) + \
+         (["-DIRE_LD_IN=" + os.environ["IRE_LD_IN"]] if os.environ.get("IRE_LD_IN") else []) + \
          os.environ.get("IRE_XFLAGS", "").split()          # extra compiler flags for build-time A/B (tools/s2_xflags.sh)
 
 def _hipcc():

@@ -19,6 +19,9 @@
 #ifndef IRE_LD_ONCE
 #define IRE_LD_ONCE 2
 #endif
+#ifndef IRE_LD_IN
+#define IRE_LD_IN 0        // cache policy of conv_pc's input tile loads (build-time A/B)
+#endif
 #ifndef IRE_ST_PART
 #define IRE_ST_PART 0
 #endif

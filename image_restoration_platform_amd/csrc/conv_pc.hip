@@ -196,7 +196,7 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
             const unsigned off = ok ? (unsigned)(base_off + rel[i]) : 0xffffffffu;       // out of range: reads as zero
             if constexpr (C3_ABL & 8) { R[i] = make_uint4(off, 0x3f803f80u, i, 0x3f803f80u); }
             else {
-                const u32x4_t lv = __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, 0);
+                const u32x4_t lv = __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, IRE_LD_IN);
                 R[i] = make_uint4(lv.x, lv.y, lv.z, lv.w);
             }
             okm[i] = ok ? 0xffffffffu : 0u;
