@@ -33,6 +33,7 @@ SOURCES = [
      (["-DC3_RES_PRE=" + os.environ["C3_RES_PRE"]] if os.environ.get("C3_RES_PRE") else []) +
      (["-DC3_TEPI=" + os.environ["C3_TEPI"]] if os.environ.get("C3_TEPI") else []) +
      (["-DC3_TEPI64=" + os.environ["C3_TEPI64"]] if os.environ.get("C3_TEPI64") else []) +
+     (["-DIRE_LD_ONCE32=" + os.environ["IRE_LD_ONCE32"]] if os.environ.get("IRE_LD_ONCE32") else []) +
      (["-DC3_PROD8=" + os.environ["C3_PROD8"]] if os.environ.get("C3_PROD8") else []) +
      (["-DIRE_PC_TICKS"] if os.environ.get("IRE_RB_ABLATE") == "2" else [])),
     ("gn.hip", []),

@@ -41,8 +41,13 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #define C3_PRIO 1     // measured: priority 1 for the producer waves +0.5 % (911 -> 916 img/s); 3 the same
 #endif
 #ifndef C3_TEPI
-#define C3_TEPI 0    // 1: C = 32 line-coalesced epilogue through a wave-private LDS transpose patch (build-time A/B).  Measured NEUTRAL (same box, twice
-                     // each: RB2 314.3 / 318.8 vs 314.8 / 315.3 us, RB1 265.0 / 271.0 vs 266.6 / 267.5): the addresser's busy cycles fall, the kernel's time does not
+#define C3_TEPI 1    // C = 32 line-coalesced epilogue through a wave-private LDS transpose patch (0: the direct epilogue; build-time A/B).  With plain
+                     // (write-back) stores it measured NEUTRAL (RB2 314.3 / 318.8 vs 314.8 / 315.3 us): the addresser's busy cycles fall, the kernel's time
+                     // does not.  With its whole-line stores written THROUGH (IRE_ST_LINE) it pays on the residual kernel: same box, three times
+                     // each, RB2 314.0 / 317.6 / 317.3 -> 302.3 / 302.0 / 302.5 us, RB1 unchanged, step 1014.8 / 1018.2 / 1016.8 -> 1023.9 / 1022.3 / 1022.0 img/s
+#endif
+#ifndef IRE_LD_ONCE32
+#define IRE_LD_ONCE32 2      // the C = 32 line-coalesced residual loads are non-temporal (build-time A/B: RB2 304.5 / 303.4 -> 299.0 / 301.7 us, step +0.3 %)
 #endif
 #ifndef C3_TEPI64
 #define C3_TEPI64 1  // C = 64: line-coalesced epilogue through the item's released input tile (0: the direct epilogue; build-time A/B)
@@ -452,7 +457,7 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
 #pragma unroll
                     for (int k = 0; k < RES_PRE; ++k) {
                         const bool ok = trow[m] && tcol + 8 * k < a.Wout;
-                        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ok ? toffs[m] + (unsigned)(8 * k * 2 * C) : 0xffffffffu, 0, 0);
+                        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ok ? toffs[m] + (unsigned)(8 * k * 2 * C) : 0xffffffffu, 0, IRE_LD_ONCE32);
                         erv[k][m] = make_uint4(v.x, v.y, v.z, v.w);
                     }
             } else

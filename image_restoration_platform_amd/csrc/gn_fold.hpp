@@ -16,6 +16,10 @@ namespace ire {
 // smem: >= nthr * 16 + 64 bytes of LDS not otherwise in use yet; ends with a barrier, the coefficient stores retired.
 // nthr_used: the threads that take part (a power of two <= blockDim.x; 0 = all of them): the rest only join the barriers.
 __device__ __forceinline__ void gn_fold(const ConvArgs& a, unsigned char* smem, int img_lo, int img_hi, int nthr_used = 0) {
+#if defined(IRE_FOLD_ABL) && IRE_FOLD_ABL == 1      // timing ablation (results wrong by design): the consumers read stale coefficients
+    __syncthreads();
+    return;
+#endif
     const int tid = threadIdx.x, nthr = nthr_used ? nthr_used : (int)blockDim.x;
     const bool act = tid < nthr;
     double* red = reinterpret_cast<double*>(smem);                       // [nthr][2]
