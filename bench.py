@@ -55,6 +55,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-buffer (PCIe-inclusive) sub-record measured after the timed region")
     ap.add_argument("--no-profile", action="store_true", help="skip the in-engine HIP-event kernel timing")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel family (more events, ~5 %% slower)")
+    ap.add_argument("--profile-every", type=int, default=4, help="time the dominant family's launches on every N-th timed step (an event record is a packet "
+                    "between two kernels: on every step it costs 1.35 %% of the step); 1 = every step")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # tests only: gloo + a sleep instead of the GPU step
     args = ap.parse_args(argv)
     if args.size is None:
@@ -291,8 +293,11 @@ def run_restore(ctx, eng):
     def start_profile():                       # after the warm-up: the in-engine per-kernel event timing covers the timed steps only
         if not a.no_profile:
             eng.profile_reset()
-            eng.profile_enable(1 if a.profile_all else 2)
+            eng.profile_enable(1 if a.profile_all else 2 | (max(1, a.profile_every) << 8))
 
+    if a.streams > 1:
+        a.profile_every = 1          # (with several lanes a step is several passes of the network: every one of them is timed)
+    n_prof = a.steps if a.profile_all else len(range(0, a.steps, max(1, a.profile_every)))     # timed steps whose launches carry events
     dt = ctx.timed(step, before=start_profile)
     prof = None
     if not a.no_profile:
@@ -334,9 +339,11 @@ def run_restore(ctx, eng):
             "traffic": traffic, "traffic_source": traffic_src, "launches": c3["launches"], "avg_launch_us": 1e3 * c3["ms"] / max(1, c3["launches"]),
             "algorithmic_gflop_per_launch": c3["flops"] / max(1, c3["launches"]) / 1e9,
             "hbm_algorithmic_GBs": c3["bytes"] / (c3["ms"] * 1e-3) / 1e9 if c3["ms"] > 0 else 0.0,
-            "family_ms_per_step": {k: v["ms"] / a.steps for k, v in prof.items()},
+            "family_ms_per_step": {k: v["ms"] / n_prof for k, v in prof.items()},
+            "timed_steps": n_prof, "timed_steps_note": "HIP events bracket every launch of the family on %d of the %d timed steps (every %s); "
+                           "each event record is a packet between two kernels" % (n_prof, a.steps, "step" if a.profile_all or a.profile_every <= 1 else "%d-th" % a.profile_every),
         }
-        res["roofline"].update(per_level_roofline(groups, a.steps, (tr or {}).get("per_group")))
+        res["roofline"].update(per_level_roofline(groups, n_prof, (tr or {}).get("per_group")))
         res["whole_net_mfma_frac"] = (f3 + f1) * B * a.steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS
     if ctx.world == 1 and not a.no_host_path:
         res["host_path"] = host_path(eng, S, B)

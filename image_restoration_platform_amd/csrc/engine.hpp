@@ -164,7 +164,7 @@ public:
     void debug_capture(bool on) { capture_ = on; captured_.clear(); }
     bool debug_activation(const std::string& name, float* out, size_t* count);
 
-    void profile_enable(int mode);   // 0 off, 1 every kernel family, 2 the 3x3 conv family only
+    void profile_enable(int mode);   // low byte: 0 off, 1 every kernel family, 2 the 3x3 conv family only; bits 8..: N = time every N-th network pass (mode 2)
     void profile_reset();
     void profile_query(int fam, double* ms, int64_t* launches, double* flops, double* bytes);
     std::string profile_report();    // JSON array, one object per layer group (ire_profile_report)
@@ -293,6 +293,8 @@ private:
     bool capture_ = false;
     std::map<std::string, std::vector<float>> captured_;
     int prof_on_ = 0;
+    int prof_every_ = 1, prof_pass_ = 0;   // mode 2: time every prof_every_-th pass of the network
+    bool prof_skip_ = false;
     bool prof_open_ = false;
     bool prof_chain_ = false;          // the stream's last operation is prof_.back()'s end event (prof_chain_stream_): the next record starts there
     hipStream_t prof_chain_stream_ = nullptr;

@@ -212,7 +212,8 @@ int ire_debug_capture(ire_engine* e, int on);
 int ire_debug_activation(ire_engine* e, const char* name, float* out, size_t* count);
 /* Accumulated HIP-event time (ms) and launch count per kernel family since the last reset:
  * family in {"classifier","conv3x3","conv1x1","stem","head","gn_finalize","fusion","all"}. */
-int ire_profile_enable(ire_engine* e, int mode /* 0 off, 1 all families, 2 conv3x3 only (least overhead) */);
+int ire_profile_enable(ire_engine* e, int mode /* low byte: 0 off, 1 all families, 2 conv3x3 only (least overhead);
+                                                   bits 8..: N > 1 = in mode 2 time only every N-th pass of the network */);
 int ire_profile_query(ire_engine* e, const char* family, double* ms_out, int64_t* launches_out,
                       double* flops_out, double* bytes_out);
 int ire_profile_reset(ire_engine* e);
