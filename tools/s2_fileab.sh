@@ -7,8 +7,8 @@ for v in new alt new alt; do
   python -m image_restoration_platform_amd.build > /dev/null 2>&1 || { echo build failed; exit 1; }
   if [ "$v" = new ] && [ -n "$4" ] && [ ! -f /tmp/fileab_tested ]; then timeout -k 10 900 python -m pytest $4 -x -q -m gpu > $O/fab_tests.log 2>&1; tail -3 $O/fab_tests.log; touch /tmp/fileab_tested; fi
   cd /tmp; export TMPDIR=/tmp; rm -rf $O/fab_$v
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/fab_$v -o r --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/fab_$v.log 2>&1
-  cd $R; timeout -k 10 200 python bench.py --no-cpu-baseline --no-profile > $O/fab_$v.json 2>> $O/fab_err.log
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/fab_$v -o r --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-path > $O/fab_$v.log 2>&1
+  cd $R; timeout -k 10 200 python bench.py --no-cpu-baseline --no-host-path --no-profile > $O/fab_$v.json 2>> $O/fab_err.log
   python3 - <<PY
 import csv, glob, json
 f = glob.glob("$O/fab_$v/**/r_kernel_stats.csv", recursive=True)[0]
