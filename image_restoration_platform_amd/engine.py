@@ -279,7 +279,8 @@ class Engine:
         return out
 
     def profile_enable(self, mode=1):
-        """0 off, 1 every kernel family, 2 the 3x3 conv family only (fewest HIP events)."""
+        """Low byte: 0 off, 1 every kernel family, 2 the 3x3 conv family only (fewest HIP events); `mode | (N << 8)`: in mode 2
+        bracket the launches of every N-th pass of the network only (an event record is a packet between two kernels)."""
         self._check(self._lib.ire_profile_enable(self._h, int(mode)))
 
     def profile_reset(self):

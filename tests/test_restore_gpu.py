@@ -262,6 +262,35 @@ def test_capacity_query_and_gauges(engine):
     assert s1["imagesPerSec"] > 0 and s1["maxBatch"] == 8 and s1["queueDepth"] == 0
 
 
+def test_profiler_modes_and_sampled_passes(engine):
+    """ire_profile_enable: mode 2 brackets the 3x3 conv family's launches (38 per pass of the network), `2 | N << 8` those of every
+    N-th pass only (what bench.py's default run does: an event record is a packet between two kernels); the per-group report adds
+    up to the family's totals; profiling changes no pixel."""
+    imgs = synth.batch(2, 128, 128, start=7)
+    ref = engine.restore(imgs)
+    engine.profile_reset(); engine.profile_enable(2)
+    for _ in range(4):
+        out = engine.restore(imgs)
+    engine.profile_enable(0)
+    every = engine.profile_query("conv3x3")
+    assert np.array_equal(out, ref)
+    assert every["launches"] == 4 * 38 and every["ms"] > 0 and engine.profile_query("stem")["launches"] == 0
+    rep = engine.profile_report()
+    assert sum(g["launches"] for g in rep) == every["launches"] and abs(sum(g["ms"] for g in rep) - every["ms"]) < 1e-3 * every["ms"] + 1e-6
+    assert all(g["flops_executed"] <= g["flops"] + 1 for g in rep)
+    engine.profile_reset(); engine.profile_enable(2 | (3 << 8))
+    for _ in range(7):                                   # passes 0, 3, 6 carry events
+        out = engine.restore(imgs)
+    engine.profile_enable(0)
+    assert np.array_equal(out, ref)
+    assert engine.profile_query("conv3x3")["launches"] == 3 * 38
+    engine.profile_reset(); engine.profile_enable(1)
+    engine.restore(imgs)
+    engine.profile_enable(0)
+    assert engine.profile_query("stem")["launches"] == 1 and engine.profile_query("head")["launches"] == 1
+    engine.profile_reset()
+
+
 def test_2048_single_image_and_512_batch(engine):
     """BASELINE cfg4 shape (2048x2048, untiled, bf16) and cfg1 shape (512x512 bs 8): run, deterministic,
     and a 64x64 interior crop of the 512 case agrees with restoring... (receptive field is global through
