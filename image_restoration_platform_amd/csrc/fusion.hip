@@ -344,19 +344,21 @@ __device__ __forceinline__ unsigned cls_pack_bytes(unsigned a, unsigned b, unsig
 // walks every den with the reciprocal pushed 2 ulp either way).
 template <int K>
 __device__ __forceinline__ unsigned fuse_byte(const unsigned* __restrict__ s_w, unsigned w0, unsigned a, unsigned b, unsigned d) {
-    unsigned num, den;
+    unsigned n, den;                       // n = weighted sum + den / 2, built as one multiply-add chain on top of den >> 1
     if constexpr (K == 2) {
         const unsigned m = (a + b + 1u) >> 1;
         const unsigned wa = s_w[__builtin_amdgcn_sad_u8(a, m, 0u)], wb = s_w[__builtin_amdgcn_sad_u8(b, m, 0u)];
-        num = __umul24(wa, a) + __umul24(wb, b); den = wa + wb;
+        den = wa + wb;
+        n = __umul24(wb, b) + (__umul24(wa, a) + (den >> 1));
     } else {
         // the weighted sum does not care which view a value came from: sorted, the median's own weight is WLUT[0] (read once per
         // thread), so two table reads per byte, and the two distances are plain differences
         const unsigned lo = min(min(a, b), d), hi = max(max(a, b), d), m = max(min(a, b), min(max(a, b), d));      // v_min3 / v_max3 / v_med3
         const unsigned wl = s_w[m - lo], wh = s_w[hi - m];
-        num = __umul24(wl, lo) + __umul24(wh, hi) + __umul24(w0, m); den = wl + wh + w0;
+        den = wl + wh + w0;
+        n = __umul24(w0, m) + (__umul24(wh, hi) + (__umul24(wl, lo) + (den >> 1)));
     }
-    const float nf = (float)(num + (den >> 1)) + 0.5f;
+    const float nf = (float)n + 0.5f;
     return (unsigned)(nf * __builtin_amdgcn_rcpf((float)den));
 }
 
@@ -472,6 +474,8 @@ void Engine::fuse_launch(const uint8_t* d_views, int nsets, int k, int h, int w,
     prof_begin(FAM_FUSION, s, 0, (double)nsets * (k + 1) * px * 3);
     const unsigned* d_wluts = nullptr;
     if (nsets > 1) {      // one table per set (its own noise score); a single call carries its table in the kernel arguments
+        // (copied on a stream of their own, beside the luma and SAD kernels, with the blend waiting on an event: measured, the chain is
+        //  8 us LONGER -- the cross-stream wait costs more than the ~4 us copy in front: profiles/r03_experiments.md)
         IRE_HIP(hipMemcpyAsync(d_fwlut_, host_wluts, sizeof(unsigned) * 256 * nsets, hipMemcpyHostToDevice, s));   // pageable source: staged before the call returns
         d_wluts = d_fwlut_;
     }
