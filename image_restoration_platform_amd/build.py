@@ -37,7 +37,7 @@ SOURCES = [
      (["-DC3_PROD8=" + os.environ["C3_PROD8"]] if os.environ.get("C3_PROD8") else []) +
      (["-DIRE_PC_TICKS"] if os.environ.get("IRE_RB_ABLATE") == "2" else [])),
     ("gn.hip", []),
-    ("fusion.hip", []),
+    ("fusion.hip", (["-DFUSE_FL=" + os.environ["FUSE_FL"]] if os.environ.get("FUSE_FL") else [])),
     ("preprocess.hip", []),
     ("engine.cpp", []),
     ("strips.cpp", []),

@@ -102,6 +102,9 @@ struct SadCfg {
     static_assert(SR * TWD % 256 == 0 && M % 4 == 0, "tile shape");
 };
 
+#ifndef FUSE_FL
+#define FUSE_FL 16      // loads in flight per thread in the last workgroup's row sum (build-time A/B)
+#endif
 constexpr int FUSE_SAD_GRID = 512;   // workgroups per view at most (= rows of `part` per view)
 
 template <int MODE>
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256) void fusion_sad_kernel(const uint8_t* __restri
     const int total = (k - 1) * G * N;
     // FL loads in flight per thread (one round trip each otherwise); the view / candidate of element i = (vv G + g) N + c are
     // stepped, not divided out (i advances by 256: c by 256 % N): this code runs once, cold -- every instruction counts.
-    constexpr int FL = 16;
+    constexpr int FL = FUSE_FL;
     const int GN = G * N;
     int ci = tid % N, i0 = tid;
     for (int base = 0; base < total; base += 256 * FL) {
