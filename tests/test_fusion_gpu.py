@@ -137,3 +137,23 @@ def test_device_pointers_of_any_alignment(engine):
         got = obuf[off_out:off_out + ref.size].cpu().numpy().reshape(ref.shape)
         assert np.array_equal(shifts.cpu().numpy(), rsh) and np.array_equal(got, ref), (off_in, off_out)
         assert int(obuf[:off_out].sum()) == 0 and int(obuf[off_out + ref.size:].sum()) == 0      # nothing written outside
+
+
+def test_batched_two_views_sixteen_sets_and_extreme_shifts(engine):
+    """The batched entry at its limits: 16 view sets (the maximum) of TWO views each, shifts up to the search range's edge
+    (+-16 coarse +-3 fine) on a small image, so that most 4-pixel groups of the blend touch the replicate-clamped border; every
+    set against the oracle."""
+    import torch
+    rng = np.random.default_rng(5)
+    sets, noise = [], []
+    for i in range(16):
+        sh = (int(rng.integers(-19, 20)), int(rng.integers(-19, 20)))
+        sets.append(synth.fusion_views(72, 88, shifts=((0, 0), sh), seed=100 + i))
+        noise.append(float(rng.uniform(0.0, 1.0)))
+    out, shf = engine.fuse_batch_tensor(torch.from_numpy(np.stack(sets)).cuda(), noise)
+    torch.cuda.synchronize()
+    out, shf = out.cpu().numpy(), shf.cpu().numpy()
+    for i in range(16):
+        ref, rsh = ofu.fuse(sets[i], noise[i])
+        assert np.array_equal(shf[i], rsh), (i, shf[i], rsh)
+        assert np.array_equal(out[i], ref), (i, int(np.abs(out[i].astype(int) - ref.astype(int)).max()))
