@@ -28,6 +28,9 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
+#ifndef DN_LD_NT
+#define DN_LD_NT 0     // 1: the input rows non-temporal (build-time A/B)
+#endif
 constexpr int DN_THREADS = 512;
 constexpr int DN_TH = 16, DN_TW = 32;                  // output tile
 constexpr int DN_IH = DN_TH + 1, DN_IW = DN_TW + 1;    // phase-image halo tile: offsets -1 .. 0
@@ -144,7 +147,11 @@ __global__ __launch_bounds__(DN_THREADS) void conv_down_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < DN_IN_ITERS; ++i) {
             const unsigned off = ((okp >> i) & 1u) ? coff[i] + delta : 0xffffffffu;
+#if DN_LD_NT
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen nt" : "+v"(R.v[i]) : "v"(off), "s"(irsrc) : "memory");
+#else
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "+v"(R.v[i]) : "v"(off), "s"(irsrc) : "memory");      // out of range reads as zero: the padding
+#endif
         }
     };
     auto store_chunk = [&](int i, const DnRegs& R, uint4* lds_in) {
