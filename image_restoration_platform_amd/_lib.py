@@ -6,6 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IRE_LIB") or os.path.join(HERE, "lib", "libire.so")   # IRE_LIB: A/B another build of the same ABI (tools/ab_bench.sh)
 
 IRE_OK, IRE_ERR_INVALID_INPUT, IRE_ERR_TIMEOUT, IRE_ERR_UNAVAILABLE, IRE_ERR_INTERNAL = range(5)
+IRE_ABI_VERSION = 3      # include/ire.h; load() refuses a library of another version (tests/test_abi.py cross-checks the three copies)
 
 
 class IreConfig(ctypes.Structure):
@@ -61,6 +62,10 @@ SYMBOLS = {
     "ire_strips_get_output": (_i, [_vp, _vp, _vp]),
     "ire_get_stats": (_i, [_vp, ctypes.POINTER(IreEngineStats)]),
     "ire_poll": (_i, [_vp, _vp, _i, _u8p, _vp, ctypes.POINTER(IreTimings)]),
+    "ire_job_release": (_i, [_vp, _vp]),
+    "ire_affinity_plan": (_i, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int32),
+                               ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
+    "ire_engine_affinity": (_i, [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int32)]),
     "ire_debug_classifier_sums": (_i, [_vp, _i, _vp]),
     "ire_debug_capture": (_i, [_vp, _i]),
     "ire_debug_activation": (_i, [_vp, ctypes.c_char_p, _vp, ctypes.POINTER(ctypes.c_size_t)]),
@@ -92,5 +97,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError => the library does not export what ire.h declares
         fn.restype = res
         fn.argtypes = args
+    if lib.ire_abi_version() != IRE_ABI_VERSION:
+        raise EngineLibraryMissing(f"service unavailable: {LIB_PATH} has ABI version {lib.ire_abi_version()}, this binding needs {IRE_ABI_VERSION} "
+                                   "-- rebuild with `python -m image_restoration_platform_amd.build`")
     _lib = lib
     return lib

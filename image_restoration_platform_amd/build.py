@@ -21,7 +21,8 @@ SOURCES = [
      (["-DIRE_RB_NGP64=" + os.environ["IRE_RB_NGP64"]] if os.environ.get("IRE_RB_NGP64") else [])),
     ("conv_w4.hip", (["-DIRE_W4_STAMPS"] if os.environ.get("IRE_RB_ABLATE") else []) +
      (["-DIRE_W4_TICKS"] if os.environ.get("IRE_RB_ABLATE") == "2" else []) +
-     (["-DW4_TEPI=" + os.environ["IRE_W4_TEPI"]] if os.environ.get("IRE_W4_TEPI") else [])),
+     (["-DW4_TEPI=" + os.environ["IRE_W4_TEPI"]] if os.environ.get("IRE_W4_TEPI") else []) +
+     (["-DIRE_W4_TL"] if os.environ.get("IRE_W4_TL") else [])),
     ("conv_up.hip", (["-DIRE_UP_ABL=" + os.environ["IRE_UP_ABL"]] if os.environ.get("IRE_UP_ABL") else []) +
      (["-DIRE_UP_D=" + os.environ["IRE_UP_D"]] if os.environ.get("IRE_UP_D") else []) +
      (["-DIRE_UP_TEPI=" + os.environ["IRE_UP_TEPI"]] if os.environ.get("IRE_UP_TEPI") else [])),
@@ -36,6 +37,7 @@ SOURCES = [
      (["-DIRE_LD_ONCE32=" + os.environ["IRE_LD_ONCE32"]] if os.environ.get("IRE_LD_ONCE32") else []) +
      (["-DC3_PROD8=" + os.environ["C3_PROD8"]] if os.environ.get("C3_PROD8") else []) +
      (["-DIRE_PC_TICKS"] if os.environ.get("IRE_RB_ABLATE") == "2" else [])),
+    ("conv_pk.hip", (["-DPK_ABL=" + os.environ["PK_ABL"]] if os.environ.get("PK_ABL") else [])),
     ("gn.hip", []),
     ("fusion.hip", (["-DFUSE_FL=" + os.environ["FUSE_FL"]] if os.environ.get("FUSE_FL") else [])),
     ("preprocess.hip", []),

@@ -7,6 +7,13 @@
 #include <memory>
 #include <thread>
 
+#include <pthread.h>
+#include <sched.h>
+
+#include <cstdlib>
+
+#include "affinity.hpp"
+#include "batcher.hpp"
 #include "engine.hpp"
 #include "fusion.hpp"
 #include "strips.hpp"
@@ -16,90 +23,7 @@ namespace ire {
 static thread_local std::string g_last_error;
 void set_last_error(int code, const std::string& msg) { (void)code; g_last_error = msg; }
 
-// ---- async batcher: restoreBatch's in-flight promises (restorator.js:181-236) coalesced into
-// engine batches of up to max_batch equal-shape images.
-//
-// Data path, ONE host copy per direction: ire_submit copies the caller's pixels straight into the pinned staging slot of
-// the batch being gathered (in the caller's thread: concurrent callers copy concurrently), ire_poll copies from the batch's
-// pinned output to the caller (again in the caller's thread).  Round 2 had three copies per direction on one thread.
-//
-// A slot is FREE -> OPEN (gathering: submits reserve an index and stage into it; the launcher issues each staged image's
-// H2D copy at once, under the previous batch's compute) -> CLOSED (launching) -> INFLIGHT (kernels + D2H enqueued) -> DONE
-// (results in pin_out, waiting for its jobs' ire_poll) -> FREE.  Two threads: the launcher decides when a gathering batch
-// goes (below), the completer waits for the oldest in-flight batch's D2H and completes its jobs.
-//
-// When a batch goes: at once when it is full (the stream runs it behind the previous batch: no bubble); otherwise it keeps
-// gathering while the GPU still computes the previous batch (launching then would only split what a closed-loop caller --
-// 3 jobs per restoreBatch, 5 per worker -- is about to resubmit), and when the GPU is idle after a short bounded linger:
-// kLingerQuietUs after the last arrival, at most kLingerMaxUs after the first.
-struct BatchSlot;
-struct Job {
-    int h, w, is_jpeg;
-    bool has_scores = false;
-    bool staged = false;              // input bytes are in the slot's pinned buffer (or in `in` on the overflow path)
-    BatchSlot* slot = nullptr;        // where the input was staged and the output will be; null: overflow (no free slot at submit) / evicted
-    int idx = -1;
-    std::vector<uint8_t> in, out;     // overflow input / evicted output only
-    double scores[7];
-    ire_timings t{};
-    int status = -1;  // -1 pending, else ire_status
-    std::string err;
-};
-
-}  // namespace ire
-
-struct ire_job { std::shared_ptr<ire::Job> j; };
-// A strip session belongs to an engine: ire_shutdown and ire_load_weights must not pull the engine (or its layer program)
-// from under an open session.  The engine keeps a registry of its open sessions; shutdown closes their inner objects (the
-// caller's handle stays valid as an empty shell: every later call on it returns IRE_ERR_INVALID_INPUT "invalid strip
-// session handle" and ire_strips_close only frees the shell), load_weights refuses while sessions are open.
-struct ire_strips { std::unique_ptr<ire::StripSession> s; ire_engine* owner = nullptr; };
-static std::mutex g_strips_mu;       // guards every ire_engine::sessions list and every ire_strips::s / owner
-
-namespace ire {
-
-constexpr int kSlots = 8;             // gathering | computing | up to six waiting for their polls (a caller that submits a burst before its first poll)
-constexpr int kSlotsEager = 3;        // staging allocated at the first job of a shape; the other slots get theirs when first needed
-constexpr int kLingerQuietUs = 250, kLingerMaxUs = 1500;
-
-struct BatchSlot {
-    enum State { FREE, OPEN, CLOSED, INFLIGHT, DONE } state = FREE;
-    uint8_t *pin_in = nullptr, *pin_out = nullptr, *d_in = nullptr, *d_out = nullptr, *pin_jp = nullptr, *d_jp = nullptr;
-    double* pin_sc = nullptr;
-    double* pin_sc_in = nullptr;          // scores the jobs brought along (ire_submit(..., scores, ...))
-    uint8_t has_sc[64] = {};
-    size_t cap = 0;                       // bytes of each image buffer
-    hipEvent_t ev_in = nullptr, ev_c0 = nullptr, ev_c1 = nullptr, ev_out = nullptr;
-    std::vector<std::shared_ptr<Job>> jobs;   // index order = position in the batch
-    int h = 0, w = 0;
-    int h2d_issued = 0;                   // images whose H2D copy is already on the copy-in stream
-    int unread = 0, reading = 0;          // DONE: jobs that have not fetched their output yet / polls copying right now
-    std::chrono::steady_clock::time_point first_arrival, last_arrival;
-    int status = IRE_OK;
-    std::string err;
-};
-
-}  // namespace ire
-
-struct ire_engine {
-    std::unique_ptr<ire::Engine> eng;
-    // batcher
-    std::mutex qmu;
-    std::condition_variable qcv, dcv, ccv;     // launcher wake-ups | job completion | completer wake-ups
-    ire::BatchSlot slots[ire::kSlots];
-    std::deque<int> open_order;                // OPEN slots, oldest first
-    std::deque<int> inflight;                  // INFLIGHT slots, launch order
-    std::deque<std::shared_ptr<ire::Job>> overflow;   // submitted while no slot was free: staged by the launcher later
-    int last_launched = -1;
-    std::thread worker, completer;
-    hipStream_t cs = nullptr, os = nullptr;
-    bool stop = false, launcher_done = false;
-    int device = 0;
-    std::vector<ire_strips*> sessions;     // open strip sessions (g_strips_mu)
-    ~ire_engine();
-};
-
-namespace ire {
+// ---- async batcher (batcher.hpp): the state machine is a template over its backend; this file provides the HIP one -------
 
 // One engine call = one critical section on the host (mutex) AND on the GPU (Engine::enter/leave): the caller's stream first
 // waits for the previous call's completion event, so calls from several threads / streams never interleave kernels on
@@ -112,239 +36,195 @@ static void on_stream(Engine& E, hipStream_t s, F&& f) {
     E.leave(s);
 }
 
-static void slot_reserve(BatchSlot& S, size_t bytes, int max_batch) {
-    if (!S.ev_in) {
-        IRE_HIP(hipEventCreateWithFlags(&S.ev_in, hipEventDisableTiming));
-        IRE_HIP(hipEventCreate(&S.ev_c0));
-        IRE_HIP(hipEventCreate(&S.ev_c1));
-        IRE_HIP(hipEventCreateWithFlags(&S.ev_out, hipEventDisableTiming));
-        IRE_HIP(hipHostMalloc((void**)&S.pin_jp, (size_t)max_batch));
-        IRE_HIP(hipHostMalloc((void**)&S.pin_sc, sizeof(double) * 7 * (size_t)max_batch));
-        IRE_HIP(hipHostMalloc((void**)&S.pin_sc_in, sizeof(double) * 7 * (size_t)max_batch));
-        IRE_HIP(hipMalloc((void**)&S.d_jp, (size_t)max_batch));
-    }
-    if (bytes <= S.cap) return;
-    if (S.pin_in) { (void)hipHostFree(S.pin_in); (void)hipHostFree(S.pin_out); (void)hipFree(S.d_in); (void)hipFree(S.d_out); }
-    S.cap = 0; S.pin_in = S.pin_out = S.d_in = S.d_out = nullptr;
-    IRE_HIP(hipHostMalloc((void**)&S.pin_in, bytes));
-    IRE_HIP(hipHostMalloc((void**)&S.pin_out, bytes));
-    IRE_HIP(hipMalloc((void**)&S.d_in, bytes));
-    IRE_HIP(hipMalloc((void**)&S.d_out, bytes));
-    S.cap = bytes;
-}
+struct DeviceGuard {       // staging is allocated on first use of a shape, possibly from a caller's thread: leave that thread's current device as it was
+    int prev = -1;
+    explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); (void)hipSetDevice(dev); }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 
-static void slot_free(BatchSlot& S) {
-    if (S.pin_in) { (void)hipHostFree(S.pin_in); (void)hipHostFree(S.pin_out); (void)hipFree(S.d_in); (void)hipFree(S.d_out); }
-    if (S.ev_in) {
-        (void)hipEventDestroy(S.ev_in); (void)hipEventDestroy(S.ev_c0); (void)hipEventDestroy(S.ev_c1); (void)hipEventDestroy(S.ev_out);
-        (void)hipHostFree(S.pin_jp); (void)hipHostFree(S.pin_sc); (void)hipHostFree(S.pin_sc_in); (void)hipFree(S.d_jp);
-    }
-    S = BatchSlot{};
-}
+struct HipSlot {
+    uint8_t *d_in = nullptr, *d_out = nullptr, *d_jp = nullptr;
+    hipEvent_t ev_in = nullptr, ev_c0 = nullptr, ev_c1 = nullptr, ev_out = nullptr;
+};
 
-// (qmu held) an OPEN slot of this shape with room, else a FREE one opened for it, else -1.  May allocate staging (first use
-// of a shape: once).  A DONE slot nobody is reading is evicted when nothing else is left: its unfetched outputs move to
-// their jobs' own vectors (the extra copy only a caller that lets four batches pile up unpolled ever pays).
-static int slot_for(ire_engine* E, int h, int w) {
-    const int mb = E->eng->max_batch();
-    for (auto it = E->open_order.rbegin(); it != E->open_order.rend(); ++it) {
-        BatchSlot& S = E->slots[*it];
-        if (S.h == h && S.w == w && (int)S.jobs.size() < mb) return *it;
-    }
-    int pick = -1;
-    const size_t need = (size_t)h * w * 3 * (size_t)mb;
-    for (int i = 0; i < kSlots && pick < 0; ++i) if (E->slots[i].state == BatchSlot::FREE && E->slots[i].cap >= need) pick = i;     // one whose staging exists
-    for (int i = 0; i < kSlots && pick < 0; ++i) if (E->slots[i].state == BatchSlot::FREE) pick = i;
-    if (pick < 0) {
-        for (int i = 0; i < kSlots && pick < 0; ++i) {
-            BatchSlot& S = E->slots[i];
-            if (S.state != BatchSlot::DONE || S.reading) continue;
-            const size_t ib = (size_t)S.h * S.w * 3;
-            for (auto& j : S.jobs)
-                if (j->slot == &S) { j->out.assign(S.pin_out + ib * j->idx, S.pin_out + ib * (j->idx + 1)); j->slot = nullptr; }
-            S.jobs.clear(); S.unread = 0; S.state = BatchSlot::FREE;
-            pick = i;
-        }
-    }
-    if (pick < 0) return -1;
-    BatchSlot& S = E->slots[pick];
-    {
-        // staging is allocated on first use of a shape, possibly from a caller's thread: leave that thread's current device as it was
-        int prev = -1;
-        (void)hipGetDevice(&prev);
-        (void)hipSetDevice(E->device);
-        try { slot_reserve(S, (size_t)h * w * 3 * (size_t)mb, mb); } catch (...) { if (prev >= 0) (void)hipSetDevice(prev); throw; }
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-    S.state = BatchSlot::OPEN; S.h = h; S.w = w; S.jobs.clear(); S.h2d_issued = 0; S.unread = S.reading = 0;
-    S.status = IRE_OK; S.err.clear();
-    S.first_arrival = S.last_arrival = std::chrono::steady_clock::now();
-    E->open_order.push_back(pick);
-    return pick;
-}
-
-// (qmu held) reserve the next index of slot si for job j
-static void slot_add(ire_engine* E, int si, const std::shared_ptr<Job>& j) {
-    BatchSlot& S = E->slots[si];
-    j->slot = &S; j->idx = (int)S.jobs.size();
-    S.pin_jp[j->idx] = (uint8_t)j->is_jpeg;
-    S.has_sc[j->idx] = j->has_scores ? 1 : 0;
-    if (j->has_scores) std::memcpy(S.pin_sc_in + 7 * j->idx, j->scores, sizeof(double) * 7);
-    S.jobs.push_back(j);
-    S.last_arrival = std::chrono::steady_clock::now();
-    if (j->idx == 0) S.first_arrival = S.last_arrival;
-}
-
-// (launcher, qmu held) H2D of every image staged so far, in index order, on the copy-in stream: rides under the previous
-// batch's compute.  Returns false on a HIP error (recorded in the slot).
-static void slot_push_h2d(ire_engine* E, BatchSlot& S) {
-    const size_t ib = (size_t)S.h * S.w * 3;
-    int upto = S.h2d_issued;
-    while (upto < (int)S.jobs.size() && S.jobs[upto]->staged) ++upto;
-    if (upto == S.h2d_issued || S.status != IRE_OK) return;
-    const hipError_t rc = hipMemcpyAsync(S.d_in + ib * S.h2d_issued, S.pin_in + ib * S.h2d_issued, ib * (size_t)(upto - S.h2d_issued), hipMemcpyHostToDevice, E->cs);
-    if (rc != hipSuccess) { S.status = IRE_ERR_INTERNAL; S.err = std::string("internal: ") + hipGetErrorString(rc); }
-    S.h2d_issued = upto;
-}
-
-static void complete_jobs(ire_engine* E, BatchSlot& S, const ire_timings& t) {     // qmu held
-    const int n = (int)S.jobs.size();
-    for (int i = 0; i < n; ++i) {
-        Job& j = *S.jobs[i];
-        if (S.status == IRE_OK) { std::memcpy(j.scores, S.pin_sc + 7 * i, sizeof(double) * 7); j.t = t; }
-        else j.slot = nullptr;
-        j.err = S.err;
-        j.status = S.status;
-    }
-    if (S.status == IRE_OK) { S.state = BatchSlot::DONE; S.unread = n; }
-    else { S.jobs.clear(); S.state = BatchSlot::FREE; }
-}
-
-static void launcher_loop(ire_engine* E) {
-    (void)hipSetDevice(E->device);
-    using clk = std::chrono::steady_clock;
-    std::unique_lock<std::mutex> lk(E->qmu);
-    for (;;) {
-        // jobs that found no free slot at submit time: stage them now (this thread copies), oldest first
-        while (!E->overflow.empty()) {
-            std::shared_ptr<Job> j = E->overflow.front();
-            int si = -1;
-            try { si = slot_for(E, j->h, j->w); }
-            catch (const Error& e) { j->status = e.code; j->err = e.msg; E->overflow.pop_front(); E->dcv.notify_all(); continue; }
-            if (si < 0) break;
-            E->overflow.pop_front();
-            slot_add(E, si, j);
-            BatchSlot& S = E->slots[si];
-            std::memcpy(S.pin_in + (size_t)j->h * j->w * 3 * j->idx, j->in.data(), j->in.size());
-            j->in.clear(); j->in.shrink_to_fit();
-            j->staged = true;
-        }
-        if (E->open_order.empty()) {
-            if (E->stop && E->overflow.empty()) break;
-            // (overflow jobs wait for a slot: a poll or the completer frees one and notifies)
-            if (E->overflow.empty()) E->qcv.wait(lk); else E->qcv.wait_for(lk, std::chrono::microseconds(200));
-            continue;
-        }
-        const int si = E->open_order.front();
-        BatchSlot& S = E->slots[si];
-        slot_push_h2d(E, S);
-        const bool full = (int)S.jobs.size() >= E->eng->max_batch();
-        if (!full && !E->stop && S.status == IRE_OK && E->open_order.size() == 1) {
-            bool gpu_busy = false;
-            if (E->last_launched >= 0) {
-                BatchSlot& P = E->slots[E->last_launched];
-                gpu_busy = P.state == BatchSlot::INFLIGHT && hipEventQuery(P.ev_c1) == hipErrorNotReady;
+// CPU set of this engine's service threads (affinity.hpp): IRE_CPU_AFFINITY = "off" | a cpulist overrides the sysfs plan
+static CpuPlan plan_for_device(int device) {
+    CpuPlan p;
+    const char* env = std::getenv("IRE_CPU_AFFINITY");
+    if (env && (!std::strcmp(env, "off") || !std::strcmp(env, "0"))) return p;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, sizeof(bdf), device) == hipSuccess) p = affinity_plan("/sys", bdf);
+    if (env && env[0]) { const auto r = parse_cpulist(env); if (!r.empty()) p.ranges = r; return p; }
+    // A container's cpuset (a job that was given 16 of the host's CPUs) outranks the plan: only the planned CPUs this process may
+    // run on count, and a share of fewer than four of them (launcher + completer + the host's own waiter threads would queue behind
+    // each other) is no plan at all -- the threads then stay wherever the scheduler is allowed to put them.
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0) {
+        std::vector<std::pair<int, int>> keep;
+        int n = 0;
+        for (int c : p.cpus())
+            if (c >= 0 && c < CPU_SETSIZE && CPU_ISSET(c, &allowed)) {
+                if (!keep.empty() && keep.back().second == c - 1) keep.back().second = c; else keep.emplace_back(c, c);
+                ++n;
             }
-            if (gpu_busy) { E->qcv.wait_for(lk, std::chrono::microseconds(100)); continue; }
-            const auto now = clk::now();
-            const auto quiet = std::chrono::duration_cast<std::chrono::microseconds>(now - S.last_arrival).count();
-            const auto age = std::chrono::duration_cast<std::chrono::microseconds>(now - S.first_arrival).count();
-            if (quiet < kLingerQuietUs && age < kLingerMaxUs) { E->qcv.wait_for(lk, std::chrono::microseconds(50)); continue; }
-        }
-        // launch: no more reservations, wait for the copies still running in submitting threads
-        S.state = BatchSlot::CLOSED;
-        E->open_order.pop_front();
-        E->qcv.wait(lk, [&] { for (auto& j : S.jobs) if (!j->staged) return false; return true; });
-        slot_push_h2d(E, S);
-        const int n = (int)S.jobs.size();
-        const size_t ib = (size_t)S.h * S.w * 3;
-        lk.unlock();
-        try {
-            if (S.status != IRE_OK) throw Error{S.status, S.err};
-            IRE_HIP(hipMemcpyAsync(S.d_jp, S.pin_jp, (size_t)n, hipMemcpyHostToDevice, E->cs));
-            IRE_HIP(hipEventRecord(S.ev_in, E->cs));
-            hipStream_t ms = E->eng->main_stream();
-            on_stream(*E->eng, ms, [&] {
-                IRE_HIP(hipStreamWaitEvent(ms, S.ev_in, 0));
-                IRE_HIP(hipEventRecord(S.ev_c0, ms));
-                E->eng->restore_device_mixed(S.d_in, n, S.h, S.w, S.pin_sc_in, S.has_sc, S.d_jp, S.d_out, ms);   // classifies the jobs that brought no scores
-                IRE_HIP(hipMemcpyAsync(S.pin_sc, E->eng->scores_device(), sizeof(double) * 7 * n, hipMemcpyDeviceToHost, ms));
-                IRE_HIP(hipEventRecord(S.ev_c1, ms));
-            });
-            IRE_HIP(hipStreamWaitEvent(E->os, S.ev_c1, 0));
-            IRE_HIP(hipMemcpyAsync(S.pin_out, S.d_out, ib * n, hipMemcpyDeviceToHost, E->os));
-            IRE_HIP(hipEventRecord(S.ev_out, E->os));
-        } catch (const Error& e) { S.status = e.code; S.err = e.msg; }
-        catch (const std::exception& e) { S.status = IRE_ERR_INTERNAL; S.err = std::string("internal: ") + e.what(); }
-        lk.lock();
-        if (S.status == IRE_OK) {
-            S.state = BatchSlot::INFLIGHT;
-            E->inflight.push_back(si);
-            E->last_launched = si;
-            E->ccv.notify_all();
-        } else {
-            // whatever was enqueued before the failure may still touch the slot's buffers: drain before handing the error out
-            lk.unlock(); (void)hipStreamSynchronize(E->cs); (void)hipStreamSynchronize(E->eng->main_stream()); (void)hipStreamSynchronize(E->os); lk.lock();
-            complete_jobs(E, S, ire_timings{});
-            E->dcv.notify_all();
-        }
+        if (n < 4) keep.clear();
+        p.ranges = keep;
     }
-    E->launcher_done = true;
-    E->ccv.notify_all();
+    return p;
 }
 
-static void completer_loop(ire_engine* E) {
-    (void)hipSetDevice(E->device);
-    std::unique_lock<std::mutex> lk(E->qmu);
-    for (;;) {
-        E->ccv.wait(lk, [&] { return !E->inflight.empty() || E->launcher_done; });
-        if (E->inflight.empty()) break;
-        BatchSlot& S = E->slots[E->inflight.front()];
-        lk.unlock();
-        ire_timings t{};
-        const hipError_t rc = hipEventSynchronize(S.ev_out);
-        int st = IRE_OK; std::string err;
-        if (rc != hipSuccess) { st = IRE_ERR_INTERNAL; err = std::string("internal: ") + hipGetErrorString(rc); }
-        else {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, S.ev_c0, S.ev_c1) == hipSuccess) { t.restore_ms = ms; t.total_ms = ms; }
-        }
-        lk.lock();
-        if (st != IRE_OK) { S.status = st; S.err = err; }
-        E->inflight.pop_front();
-        complete_jobs(E, S, t);
-        E->dcv.notify_all();
-        E->qcv.notify_all();
-    }
+static void bind_this_thread(const CpuPlan& p) {
+    const auto cpus = p.cpus();
+    if (cpus.empty()) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int c : cpus) if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &set);
+    (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);      // (a cpuset that excludes them all: EINVAL, the thread stays where it was)
 }
+
+struct HipBatchBackend {
+    Engine& E;
+    int device;
+    CpuPlan plan;
+    hipStream_t cs = nullptr, os = nullptr;      // copy-in | copy-out
+    HipBatchBackend(Engine& e, int dev) : E(e), device(dev), plan(plan_for_device(dev)) {}
+    ~HipBatchBackend() {
+        DeviceGuard g(device);
+        if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
+        if (os) { (void)hipStreamSynchronize(os); (void)hipStreamDestroy(os); }
+    }
+    int max_batch() const { return E.max_batch(); }
+    void start() {
+        DeviceGuard g(device);
+        if (!cs) IRE_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        if (!os) IRE_HIP(hipStreamCreateWithFlags(&os, hipStreamNonBlocking));
+    }
+    void thread_enter(const char*) { (void)hipSetDevice(device); bind_this_thread(plan); }
+    // Everything new goes into locals first and is committed only when all of it exists: a failure half way (out of pinned
+    // memory at the fifth slot) frees the locals and leaves the slot exactly as it was -- usable at its old capacity, or empty.
+    void reserve(SlotBufs& b, size_t bytes, int mb) {
+        if (b.fixed && bytes <= b.cap) return;
+        DeviceGuard g(device);
+        HipSlot nh;
+        uint8_t *pj = nullptr, *pi = nullptr, *po = nullptr, *di = nullptr, *dout = nullptr;
+        double *ps = nullptr, *psi = nullptr;
+        const bool want_fixed = !b.fixed, want_img = bytes > b.cap;
+        try {
+            if (want_fixed) {
+                IRE_HIP(hipEventCreateWithFlags(&nh.ev_in, hipEventDisableTiming));
+                IRE_HIP(hipEventCreate(&nh.ev_c0));
+                IRE_HIP(hipEventCreate(&nh.ev_c1));
+                IRE_HIP(hipEventCreateWithFlags(&nh.ev_out, hipEventDisableTiming));
+                IRE_HIP(hipHostMalloc((void**)&pj, (size_t)mb));
+                IRE_HIP(hipHostMalloc((void**)&ps, sizeof(double) * 7 * (size_t)mb));
+                IRE_HIP(hipHostMalloc((void**)&psi, sizeof(double) * 7 * (size_t)mb));
+                IRE_HIP(hipMalloc((void**)&nh.d_jp, (size_t)mb));
+            }
+            if (want_img) {
+                IRE_HIP(hipHostMalloc((void**)&pi, bytes));
+                IRE_HIP(hipHostMalloc((void**)&po, bytes));
+                IRE_HIP(hipMalloc((void**)&di, bytes));
+                IRE_HIP(hipMalloc((void**)&dout, bytes));
+            }
+        } catch (...) {
+            if (nh.ev_in) (void)hipEventDestroy(nh.ev_in);
+            if (nh.ev_c0) (void)hipEventDestroy(nh.ev_c0);
+            if (nh.ev_c1) (void)hipEventDestroy(nh.ev_c1);
+            if (nh.ev_out) (void)hipEventDestroy(nh.ev_out);
+            if (pj) (void)hipHostFree(pj);
+            if (ps) (void)hipHostFree(ps);
+            if (psi) (void)hipHostFree(psi);
+            if (nh.d_jp) (void)hipFree(nh.d_jp);
+            if (pi) (void)hipHostFree(pi);
+            if (po) (void)hipHostFree(po);
+            if (di) (void)hipFree(di);
+            if (dout) (void)hipFree(dout);
+            throw;
+        }
+        HipSlot* hs = static_cast<HipSlot*>(b.impl);
+        if (!hs) { hs = new HipSlot(); b.impl = hs; }
+        if (want_fixed) {
+            hs->ev_in = nh.ev_in; hs->ev_c0 = nh.ev_c0; hs->ev_c1 = nh.ev_c1; hs->ev_out = nh.ev_out; hs->d_jp = nh.d_jp;
+            b.pin_jp = pj; b.pin_sc = ps; b.pin_sc_in = psi; b.fixed = true;
+        }
+        if (want_img) {
+            if (b.pin_in) { (void)hipHostFree(b.pin_in); (void)hipHostFree(b.pin_out); (void)hipFree(hs->d_in); (void)hipFree(hs->d_out); }
+            b.pin_in = pi; b.pin_out = po; hs->d_in = di; hs->d_out = dout; b.cap = bytes;
+        }
+    }
+    void release(SlotBufs& b) noexcept {
+        DeviceGuard g(device);
+        HipSlot* hs = static_cast<HipSlot*>(b.impl);
+        if (b.pin_in) { (void)hipHostFree(b.pin_in); (void)hipHostFree(b.pin_out); }
+        if (b.fixed) { (void)hipHostFree(b.pin_jp); (void)hipHostFree(b.pin_sc); (void)hipHostFree(b.pin_sc_in); }
+        if (hs) {
+            if (hs->d_in) { (void)hipFree(hs->d_in); (void)hipFree(hs->d_out); }
+            if (hs->ev_in) { (void)hipEventDestroy(hs->ev_in); (void)hipEventDestroy(hs->ev_c0); (void)hipEventDestroy(hs->ev_c1); (void)hipEventDestroy(hs->ev_out); (void)hipFree(hs->d_jp); }
+            delete hs;
+        }
+        b = SlotBufs{};
+    }
+    void h2d(SlotBufs& b, size_t off, size_t bytes) {
+        HipSlot& hs = *static_cast<HipSlot*>(b.impl);
+        IRE_HIP(hipMemcpyAsync(hs.d_in + off, b.pin_in + off, bytes, hipMemcpyHostToDevice, cs));
+    }
+    void launch(SlotBufs& b, int n, int h, int w, const uint8_t* has_sc) {
+        HipSlot& hs = *static_cast<HipSlot*>(b.impl);
+        const size_t ib = (size_t)h * w * 3;
+        IRE_HIP(hipMemcpyAsync(hs.d_jp, b.pin_jp, (size_t)n, hipMemcpyHostToDevice, cs));
+        IRE_HIP(hipEventRecord(hs.ev_in, cs));
+        hipStream_t ms = E.main_stream();
+        on_stream(E, ms, [&] {
+            IRE_HIP(hipStreamWaitEvent(ms, hs.ev_in, 0));
+            IRE_HIP(hipEventRecord(hs.ev_c0, ms));
+            E.restore_device_mixed(hs.d_in, n, h, w, b.pin_sc_in, has_sc, hs.d_jp, hs.d_out, ms);   // classifies the jobs that brought no scores
+            IRE_HIP(hipMemcpyAsync(b.pin_sc, E.scores_device(), sizeof(double) * 7 * n, hipMemcpyDeviceToHost, ms));
+            IRE_HIP(hipEventRecord(hs.ev_c1, ms));
+        });
+        IRE_HIP(hipStreamWaitEvent(os, hs.ev_c1, 0));
+        IRE_HIP(hipMemcpyAsync(b.pin_out, hs.d_out, ib * n, hipMemcpyDeviceToHost, os));
+        IRE_HIP(hipEventRecord(hs.ev_out, os));
+    }
+    bool computing(SlotBufs& b) noexcept { return hipEventQuery(static_cast<HipSlot*>(b.impl)->ev_c1) == hipErrorNotReady; }
+    void wait_compute(SlotBufs& b) noexcept { (void)hipEventSynchronize(static_cast<HipSlot*>(b.impl)->ev_c1); }
+    void wait_done(SlotBufs& b, ire_timings& t) {
+        HipSlot& hs = *static_cast<HipSlot*>(b.impl);
+        const hipError_t rc = hipEventSynchronize(hs.ev_out);
+        if (rc != hipSuccess) throw Error{IRE_ERR_INTERNAL, std::string("internal: ") + hipGetErrorString(rc)};
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, hs.ev_c0, hs.ev_c1) == hipSuccess) { t.restore_ms = ms; t.total_ms = ms; }
+    }
+    void drain() noexcept {
+        DeviceGuard g(device);
+        if (cs) (void)hipStreamSynchronize(cs);
+        (void)hipStreamSynchronize(E.main_stream());
+        if (os) (void)hipStreamSynchronize(os);
+    }
+};
 
 }  // namespace ire
 
+struct ire_job { std::shared_ptr<ire::Job> j; };
+// A strip session belongs to an engine: ire_shutdown and ire_load_weights must not pull the engine (or its layer program)
+// from under an open session.  The engine keeps a registry of its open sessions; shutdown closes their inner objects (the
+// caller's handle stays valid as an empty shell: every later call on it returns IRE_ERR_INVALID_INPUT "invalid strip
+// session handle" and ire_strips_close only frees the shell), load_weights refuses while sessions are open.
+struct ire_strips { std::unique_ptr<ire::StripSession> s; ire_engine* owner = nullptr; };
+static std::mutex g_strips_mu;       // guards every ire_engine::sessions list and every ire_strips::s / owner
+
+struct ire_engine {
+    std::unique_ptr<ire::Engine> eng;
+    std::unique_ptr<ire::HipBatchBackend> backend;                  // (declared before the batcher: destroyed after it)
+    std::unique_ptr<ire::Batcher<ire::HipBatchBackend>> batcher;
+    int device = 0;
+    std::vector<ire_strips*> sessions;     // open strip sessions (g_strips_mu)
+    ~ire_engine();
+};
+
 ire_engine::~ire_engine() {
-    {
-        std::lock_guard<std::mutex> lk(qmu);
-        stop = true;
-    }
-    qcv.notify_all();
-    if (worker.joinable()) worker.join();        // launches what is still gathered, then exits
-    ccv.notify_all();
-    if (completer.joinable()) completer.join();  // completes every batch in flight
-    if (eng) {
-        (void)hipSetDevice(device);
-        if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
-        if (os) { (void)hipStreamSynchronize(os); (void)hipStreamDestroy(os); }
-        for (auto& S : slots) ire::slot_free(S);
-    }
+    batcher.reset();          // launches what is gathered, completes what is in flight, frees the staging
+    backend.reset();
     std::lock_guard<std::mutex> lk(g_strips_mu);
     for (ire_strips* s : sessions) {       // invalidate: the StripSession dies with its engine, the caller's shell survives
         if (eng) { std::lock_guard<std::mutex> lk2(eng->mutex()); s->s.reset(); } else s->s.reset();
@@ -404,6 +284,8 @@ int ire_init(const ire_config* cfg, ire_engine** out) {
         std::unique_ptr<ire_engine> E(new ire_engine());
         E->eng.reset(new Engine(*cfg));
         E->device = cfg->device_index;
+        E->backend.reset(new HipBatchBackend(*E->eng, E->device));
+        E->batcher.reset(new Batcher<HipBatchBackend>(*E->backend));
         *out = E.release();
     });
 }
@@ -600,10 +482,7 @@ int ire_get_stats(ire_engine* e, ire_engine_stats* out) {
             std::lock_guard<std::mutex> lk(E.mutex());
             E.get_stats(out);
         }
-        std::lock_guard<std::mutex> lk(e->qmu);
-        int depth = (int)e->overflow.size();
-        for (int si : e->open_order) depth += (int)e->slots[si].jobs.size();
-        out->queue_depth = depth;
+        out->queue_depth = e->batcher->queue_depth();
     });
 }
 
@@ -613,41 +492,10 @@ int ire_submit(ire_engine* e, const uint8_t* rgb, int h, int w, int is_jpeg, con
         if (!rgb || !job_out) fail(IRE_ERR_INVALID_INPUT, "invalid arguments to ire_submit");
         if (h <= 0 || w <= 0 || h % 8 || w % 8 || h < 16 || w < 16 || h > 8192 || w > 8192)
             fail(IRE_ERR_INVALID_INPUT, "invalid image size for restore: height and width must be multiples of 8, >= 16");
-        auto j = std::make_shared<Job>();
-        j->h = h; j->w = w; j->is_jpeg = is_jpeg ? 1 : 0;
-        if (scores) { std::memcpy(j->scores, scores, sizeof(double) * 7); j->has_scores = true; }
-        const size_t ib = (size_t)h * w * 3;
-        uint8_t* dst = nullptr;
-        {
-            std::lock_guard<std::mutex> lk(e->qmu);
-            if (!e->worker.joinable()) {
-                int prev = -1;
-                (void)hipGetDevice(&prev);
-                (void)hipSetDevice(e->device);
-                if (!e->cs) IRE_HIP(hipStreamCreateWithFlags(&e->cs, hipStreamNonBlocking));
-                if (!e->os) IRE_HIP(hipStreamCreateWithFlags(&e->os, hipStreamNonBlocking));
-                // staging for the three slots of a steady stream now, at this first shape (pinning 3 x 2 x max_batch images takes tens
-                // of ms): the first job pays it once, instead of later jobs paying it one slot at a time in the middle of a stream
-                try { for (int i = 0; i < kSlotsEager; ++i) slot_reserve(e->slots[i], ib * (size_t)e->eng->max_batch(), e->eng->max_batch()); }
-                catch (...) { if (prev >= 0) (void)hipSetDevice(prev); throw; }
-                if (prev >= 0) (void)hipSetDevice(prev);
-                e->worker = std::thread(launcher_loop, e);
-                e->completer = std::thread(completer_loop, e);
-            }
-            const int si = e->overflow.empty() ? slot_for(e, h, w) : -1;     // (jobs already overflowing keep their order)
-            if (si >= 0) { slot_add(e, si, j); dst = e->slots[si].pin_in + ib * j->idx; }
-        }
-        if (dst) {
-            std::memcpy(dst, rgb, ib);                 // the ONE host copy of the input: caller's buffer -> pinned slot, in the caller's thread
-            std::lock_guard<std::mutex> lk(e->qmu);
-            j->staged = true;
-        } else {
-            j->in.assign(rgb, rgb + ib);               // every slot is busy: keep the pixels until the launcher finds one
-            std::lock_guard<std::mutex> lk(e->qmu);
-            e->overflow.push_back(j);
-        }
-        e->qcv.notify_all();
-        *job_out = new ire_job{j};
+        *job_out = nullptr;
+        std::unique_ptr<ire_job> hnd(new ire_job{});
+        hnd->j = e->batcher->submit(rgb, h, w, is_jpeg, scores);
+        *job_out = hnd.release();
     });
 }
 
@@ -655,34 +503,45 @@ int ire_poll(ire_engine* e, ire_job* job, int timeout_ms, uint8_t* out_rgb, doub
     return guarded([&] {
         eng(e);
         if (!job || !job->j) fail(IRE_ERR_INVALID_INPUT, "invalid job handle");
-        std::shared_ptr<Job> j = job->j;
-        BatchSlot* S = nullptr;
-        {
-            std::unique_lock<std::mutex> lk(e->qmu);
-            auto done = [&] { return j->status >= 0; };
-            if (timeout_ms < 0) e->dcv.wait(lk, done);
-            else if (!e->dcv.wait_for(lk, std::chrono::milliseconds(timeout_ms), done))
-                fail(IRE_ERR_TIMEOUT, "timeout: job still pending");
-            S = j->slot;
-            if (S) S->reading += 1;        // the slot cannot be recycled (or evicted) while this thread copies from it
-        }
-        const int st = j->status;
-        const std::string err = j->err;
-        if (st == IRE_OK) {
-            const size_t ib = (size_t)j->h * j->w * 3;
-            // the ONE host copy of the output: pinned slot -> caller's buffer, in the caller's thread
-            if (out_rgb) std::memcpy(out_rgb, S ? S->pin_out + ib * j->idx : j->out.data(), ib);
-            if (scores_out) std::memcpy(scores_out, j->scores, sizeof(double) * 7);
-            if (t) *t = j->t;
-        }
-        if (S) {
-            std::lock_guard<std::mutex> lk(e->qmu);
-            S->reading -= 1; S->unread -= 1;
-            j->slot = nullptr;
-            if (S->unread == 0 && S->state == BatchSlot::DONE) { S->jobs.clear(); S->state = BatchSlot::FREE; e->qcv.notify_all(); }
-        }
+        std::string err;
+        const int st = e->batcher->poll(job->j, timeout_ms, out_rgb, scores_out, t, &err);
+        if (st == IRE_ERR_TIMEOUT) fail(IRE_ERR_TIMEOUT, "timeout: job still pending");       // the handle stays valid: poll again or ire_job_release
         delete job;
         if (st != IRE_OK) fail(st, err);
+    });
+}
+
+int ire_job_release(ire_engine* e, ire_job* job) {
+    return guarded([&] {
+        if (!job) return;
+        // e == NULL: the engine is gone (ire_shutdown with jobs outstanding): only the handle is left to free
+        if (e && e->batcher && job->j) e->batcher->release(job->j);
+        delete job;
+    });
+}
+
+int ire_affinity_plan(const char* sysfs_root, const char* pci_bdf, char* cpulist_out, size_t cap, int32_t* numa_node_out,
+                      int32_t* slot_out, int32_t* nslots_out) {
+    return guarded([&] {
+        if (!pci_bdf || !cpulist_out || cap == 0) fail(IRE_ERR_INVALID_INPUT, "invalid arguments to ire_affinity_plan");
+        const CpuPlan p = affinity_plan(sysfs_root && sysfs_root[0] ? sysfs_root : "/sys", pci_bdf);
+        const std::string l = p.cpulist();
+        if (l.size() + 1 > cap) fail(IRE_ERR_INVALID_INPUT, "invalid buffer size for ire_affinity_plan");
+        std::memcpy(cpulist_out, l.c_str(), l.size() + 1);
+        if (numa_node_out) *numa_node_out = p.numa_node;
+        if (slot_out) *slot_out = p.slot;
+        if (nslots_out) *nslots_out = p.nslots;
+    });
+}
+
+int ire_engine_affinity(ire_engine* e, char* cpulist_out, size_t cap, int32_t* numa_node_out) {
+    return guarded([&] {
+        eng(e);
+        if (!cpulist_out || cap == 0) fail(IRE_ERR_INVALID_INPUT, "invalid arguments to ire_engine_affinity");
+        const std::string l = e->backend->plan.cpulist();
+        if (l.size() + 1 > cap) fail(IRE_ERR_INVALID_INPUT, "invalid buffer size for ire_engine_affinity");
+        std::memcpy(cpulist_out, l.c_str(), l.size() + 1);
+        if (numa_node_out) *numa_node_out = e->backend->plan.numa_node;
     });
 }
 

@@ -6,19 +6,11 @@
 #include <cstdio>
 #include <string>
 
-#include "../../include/ire.h"
+#include "errors.hpp"
 
 namespace ire {
 
-// Internal exception; converted to an ire_status + thread-local message at the C ABI.
-struct Error {
-    int code;
-    std::string msg;
-};
-
 void set_last_error(int code, const std::string& msg);
-
-[[noreturn]] inline void fail(int code, const std::string& msg) { throw Error{code, msg}; }
 
 inline void hip_check(hipError_t e, const char* what, const char* file, int line) {
     if (e != hipSuccess) {

@@ -111,6 +111,11 @@ void conv_head_launch(const ConvArgs& a, hipStream_t stream);
 // max(1, C/64), 16x32 tiles, partials layout of conv_rb_launch.  conv_pc_fits: every workgroup's images fit its coefficient table.
 void conv_pc_launch(bool resid, bool head, const ConvArgs& a, hipStream_t stream);
 bool conv_pc_fits(int C, int tiles_per_img, int nimg);
+// C = 128 / 256 ResBlock convs (fused activation) as a producer / consumer workgroup with 128-cout items (conv_pk.hip): a.w =
+// conv_w4's slabs (d_w4), a.nkc = C / 16, a.nblocks = C / 128, 16x32 tiles; results bit-identical to conv_w4's 8-wave fused form.
+// conv_pk_fits: every workgroup's images fit its coefficient table (else conv_w4 takes the launch).
+void conv_pk_launch(bool resid, const ConvArgs& a, hipStream_t stream);
+bool conv_pk_fits(int C, int tiles_per_img, int nimg);
 // CONV_UP as a sub-pixel convolution on the low-resolution grid (conv_up.hip): 4 output parities x 2x2 pre-summed taps.
 // a.Hin/Win = low-res source, a.Hout/Wout = 2x; a.nkc = Cin/32 (even), a.nblocks = cout/32, tiles of 16x32 LOW-res pixels.
 void conv_up_subpixel_launch(const ConvArgs& a, hipStream_t stream);

@@ -128,7 +128,16 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
     const int nkc = a.nkc;                         // 16-channel stages per item
     const int S = cursor.S;
     if (S == 0) return;
+#ifdef IRE_W4_TL
+    if (a.stamps && tid == 0) { a.stamps[(size_t)blockIdx.x * 32] = __builtin_amdgcn_s_memrealtime(); a.stamps[(size_t)blockIdx.x * 32 + 1] = __builtin_amdgcn_s_memtime(); }
+#endif
     if (a.gn_stats) gn_fold(a, smem, cursor.first_img, cursor.last_img);     // GroupNorm finalize of the input tensor, folded in (gn_fold.hpp)
+#ifdef IRE_W4_TL
+    if (a.stamps && tid == 0) {
+        a.stamps[(size_t)blockIdx.x * 32 + 2] = __builtin_amdgcn_s_memrealtime(); a.stamps[(size_t)blockIdx.x * 32 + 3] = __builtin_amdgcn_s_memtime();
+        a.stamps[(size_t)blockIdx.x * 32 + 26] = __builtin_amdgcn_s_getreg((31 << 11) | 20); a.stamps[(size_t)blockIdx.x * 32 + 27] = (unsigned long long)my_items;
+    }
+#endif
     using StageInfo = PersistStage;
     StageInfo sq0 = cursor.cur, sq1 = cursor.next(), sq2 = cursor.next();
 
@@ -282,6 +291,19 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
             a.stamps[(((size_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 64 + s) * 10 + k] = t;
 #else
         (void)k;
+#endif
+    };
+    // workgroup TIMELINE (diagnostic build -DIRE_W4_TL, tools/r04_tl.sh): wave 0 of every workgroup stamps the constant 100 MHz
+    // counter (comparable across CUs and XCDs) and its own shader clock at kernel entry (0), after the folded GroupNorm finalize (1),
+    // after the prologue (2: the first MFMA follows), at the end of each item (3 + k) and at exit (12); slot 13 = (XCC id, items)
+    auto tl = [&](int slot) {
+#ifdef IRE_W4_TL
+        if (a.stamps && tid == 0) {
+            a.stamps[(size_t)blockIdx.x * 32 + slot * 2] = __builtin_amdgcn_s_memrealtime();
+            a.stamps[(size_t)blockIdx.x * 32 + slot * 2 + 1] = __builtin_amdgcn_s_memtime();
+        }
+#else
+        (void)slot;
 #endif
     };
     // residual prefetch state lives across the item's last stage: the first RD-1 groups are requested BEFORE that stage's
@@ -740,6 +762,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
         if constexpr (FUSED) cnext = fetch_coeffs(sq1);
     }
     __syncthreads();
+    tl(2);
     // nkc is even (Cin/16 with Cin >= 128), so an item starts on an even stage and ends on an odd one
     for (int k = 0; k < my_items; ++k) {
         zero_acc(sq0.it.nb);
@@ -755,8 +778,10 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
         if constexpr (TEPI) epilogue_t(); else epilogue();
         finish(s); ++s;
         if constexpr (TEPI) flush_stats();      // after the stage barrier: every wave's chunk sums are in LDS (parity red_par ^ 1)
+        tl(3 + (k < 8 ? k : 8));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the workgroup's LDS is released
+    tl(12);
 }
 
 template <int NT, int WAVES, bool RESID, bool UPS, int DBG = 0, bool FUSED = false, bool FP8 = false>

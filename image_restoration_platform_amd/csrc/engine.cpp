@@ -95,6 +95,7 @@ Engine::Engine(const ire_config& cfg) {
     if (const char* v = std::getenv("IRE_UP_FUSE")) up_fuse_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_GN_FOLD")) gn_fold_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_PC")) pc_split_ = std::atoi(v);
+    if (const char* v = std::getenv("IRE_PK")) use_pk_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_HEAD_RB")) head_rb_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_DOWN_RB")) down_rb_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_STEM_RB")) stem_rb_ = std::atoi(v);
@@ -103,6 +104,7 @@ Engine::Engine(const ire_config& cfg) {
         stamps_cout_ = std::atoi(v);
         stamps_resid_ = std::strchr(v, 'r') != nullptr;
     }
+    if (const char* v = std::getenv("IRE_W4_TL")) stamps_tl_ = v;     // diagnostic (-DIRE_W4_TL builds): CSV path of the workgroup timeline of the LAST stamped launch
 
     IRE_HIP(hipStreamCreateWithFlags(&main_stream_, hipStreamNonBlocking));
     for (auto& ev : ev_) IRE_HIP(hipEventCreate(&ev));
@@ -135,6 +137,19 @@ Engine::Engine(const ire_config& cfg) {
 Engine::~Engine() {
     (void)hipSetDevice(device_);
     (void)hipDeviceSynchronize();
+    if (stamps_dev_ && !stamps_tl_.empty()) {       // workgroup timeline (conv_w4.hip `tl`): raw stamps, one row per workgroup and slot
+        std::vector<unsigned long long> h(8 * 2 * 64 * 10);
+        (void)hipMemcpy(h.data(), stamps_dev_, h.size() * 8, hipMemcpyDeviceToHost);
+        if (FILE* f = std::fopen(stamps_tl_.c_str(), "w")) {
+            std::fprintf(f, "wg,slot,realtime_10ns,memtime\n");
+            for (int wg = 0; wg < 256; ++wg)
+                for (int sl = 0; sl < 16; ++sl)
+                    if (h[(size_t)wg * 32 + sl * 2] || h[(size_t)wg * 32 + sl * 2 + 1]) std::fprintf(f, "%d,%d,%llu,%llu\n", wg, sl, h[(size_t)wg * 32 + sl * 2], h[(size_t)wg * 32 + sl * 2 + 1]);
+            std::fclose(f);
+        }
+        (void)hipFree(stamps_dev_);
+        stamps_dev_ = nullptr;
+    }
     if (stamps_dev_) {   // diagnostic dump: per-stage phase durations (s_memtime ticks = shader clocks / 100 MHz ref? printed raw)
         std::vector<unsigned long long> h(8 * 2 * 64 * 10);
         (void)hipMemcpy(h.data(), stamps_dev_, h.size() * 8, hipMemcpyDeviceToHost);
@@ -911,7 +926,7 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     a.stamps = nullptr;
     a.prio_young = prio_young_;
     a.w4_waves = (a.ab == nullptr) ? w4_waves_ : 8;
-    if (stamps_dev_ && rb && cw.cout == stamps_cout_ && (cw.kind == CONV_RB2) == stamps_resid_ && !stamps_taken_) {
+    if (stamps_dev_ && rb && cw.cout == stamps_cout_ && (cw.kind == CONV_RB2) == stamps_resid_ && (!stamps_taken_ || !stamps_tl_.empty())) {
         a.stamps = stamps_dev_;
         stamps_taken_ = true;
     }
@@ -965,7 +980,13 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
         if (cw.d_w8 != nullptr && a.ab != nullptr) {      // IRE_PRECISION_FP8: e4m3 operands for the C >= 128 ResBlock convs
             a.fp8 = 1; a.w = reinterpret_cast<const unsigned short*>(cw.d_w8); a.bias = cw.d_bias8; a.oscale = cw.d_oscale;
         }
-        conv_w4_launch(cw.kind == CONV_RB2, a, R.stream); kname = "conv_w4";
+        // the producer / consumer form (conv_pk.hip) takes the 128-cout bf16 launches with a fused activation whose workgroups stay
+        // within its coefficient table; same slabs, bit-identical results
+        if (use_pk_ && !a.fp8 && a.ab != nullptr && a.w4_nt != 64 && cw.cin == cw.cout && conv_pk_fits(cw.cout, a.tiles_x * a.tiles_y, g.nimg)) {
+            conv_pk_launch(cw.kind == CONV_RB2, a, R.stream); kname = "conv_pk";
+        } else {
+            conv_w4_launch(cw.kind == CONV_RB2, a, R.stream); kname = "conv_w4";
+        }
     } else if (head_rb) { a.w = cw.d_wp; if (pc_split_ & 1) { conv_pc_launch(false, true, a, R.stream); kname = "conv_pc"; } else { conv_head_launch(a, R.stream); kname = "conv_rb"; } }
     else if (down_rb) { a.w = cw.d_wd; a.nkc = cw.cin / 32; a.nblocks = cw.cout / 64; conv_down_launch(a, R.stream); kname = "conv_down"; }
     else if (stem_rb) { a.w = cw.d_wstem; conv_stem_launch(a, R.stream); kname = "conv_stem"; }

@@ -220,6 +220,7 @@ private:
     int w4_fused_min_c_ = 128;      // IRE_W4_FUSED_MINC: ResBlock convs with fused activation and cout >= this run on conv_w4's fused variant
     int w4_waves_ = 8;            // IRE_W4_WAVES=4: the one-wave-per-SIMD form, pre-activated inputs only (fused activation needs the 8-wave form)
     int w4_split_ = 1;            // IRE_W4_SPLIT=0: never use the 64-cout items
+    int use_pk_ = 1;              // C >= 128 ResBlock convs (128-cout items, fused activation) on conv_pk.hip's producer / consumer workgroups (IRE_PK=0: conv_w4.hip)
     int use_w4_ = 1;              // C >= 128 ResBlock convs on conv_w4.hip (IRE_W4=0: conv_rb.hip; IRE_W4_WAVES=4|8)
     int fp8_mx_ = 1;              // fp8: the block-scaled K = 64 MFMA (conv_f8.hip); IRE_FP8_MX=0: the same-rate 32x32x16 fp8 form in conv_w4.hip
     int down_rb_ = 1;             // stride-2 `down` convs on conv_down.hip's pipelined phase kernel (IRE_DOWN_RB=0: the v1 kernel)
@@ -290,6 +291,7 @@ private:
     unsigned long long* stamps_dev_ = nullptr;
     int stamps_cout_ = 0;
     bool stamps_resid_ = false, stamps_taken_ = false;
+    std::string stamps_tl_;
     bool capture_ = false;
     std::map<std::string, std::vector<float>> captured_;
     int prof_on_ = 0;

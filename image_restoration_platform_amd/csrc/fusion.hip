@@ -377,6 +377,10 @@ __global__ __launch_bounds__(256) void fusion_blend_kernel(const uint8_t* __rest
     __shared__ unsigned s_w[256];
     const size_t set = blockIdx.y;                       // view set of a batched call; its blend table comes from `wluts` (one call: kernel arguments)
     s_w[threadIdx.x] = wluts ? wluts[set * 256 + threadIdx.x] : wlut.w[threadIdx.x];
+    // the caller's buffer [buf_lo, buf_hi): the word-wide path reads whole aligned dwords AROUND a group's 12 bytes, which for a device
+    // pointer that is not 4-byte aligned would reach up to 3 bytes before the first view's first group or past the last view's last one
+    const uint8_t* const buf_lo = rgb;
+    const uint8_t* const buf_hi = rgb + (size_t)gridDim.y * K * H * W * 3;
     rgb += set * (size_t)K * H * W * 3; out += set * (size_t)H * W * 3; shifts += set * 6;
     __syncthreads();
     const int gpr = W >> 2;
@@ -389,9 +393,9 @@ __global__ __launch_bounds__(256) void fusion_blend_kernel(const uint8_t* __rest
         const int sy = shifts[v * 2], sx = shifts[v * 2 + 1];
         const int yy = min(max(y + sy, 0), H - 1);
         const uint8_t* row = rgb + ((size_t)v * H + yy) * W * 3;
-        if (x0 + sx >= 0 && x0 + sx + 3 <= W - 1) {
-            const uint8_t* p = row + (x0 + sx) * 3;
-            const unsigned rem = (unsigned)(reinterpret_cast<uintptr_t>(p) & 3u);
+        const uint8_t* p = row + (x0 + sx) * 3;
+        const unsigned rem = (unsigned)(reinterpret_cast<uintptr_t>(p) & 3u);
+        if (x0 + sx >= 0 && x0 + sx + 3 <= W - 1 && p - rem >= buf_lo && p - rem + (rem ? 16 : 12) <= buf_hi) {
             const unsigned* q = reinterpret_cast<const unsigned*>(p - rem);
             const unsigned d0 = q[0], d1 = q[1], d2 = q[2], d3 = rem ? q[3] : 0u;     // rem == 0: the 12 bytes end with d2
             e[v][0] = __builtin_amdgcn_alignbyte(d1, d0, rem);

@@ -181,6 +181,18 @@ class Engine:
         self._check(self._lib.ire_poll(self._h, handle, timeout_ms, _ptr(out), _ptr(scores), ctypes.byref(t)))
         return out, scores, {"classify_ms": t.classify_ms, "restore_ms": t.restore_ms, "total_ms": t.total_ms}
 
+    def release(self, job):
+        """Give a submitted job up without fetching it (after a poll() timeout the caller will not repeat): ire_job_release."""
+        handle, _, _ = job
+        self._check(self._lib.ire_job_release(self._h, handle))
+
+    def affinity(self):
+        """(cpulist, numa_node) the engine's service threads are bound to ("" / -1: no binding)."""
+        buf = ctypes.create_string_buffer(4096)
+        node = ctypes.c_int32(-1)
+        self._check(self._lib.ire_engine_affinity(self._h, buf, len(buf), ctypes.byref(node)))
+        return buf.value.decode(), int(node.value)
+
     # ---- device (torch tensors) ---------------------------------------------------------------
     @staticmethod
     def _stream_ptr(stream):

@@ -10,7 +10,7 @@ import ref from 'ref-napi';
 const P = ref.refType(ref.types.void);       // any pointer (buffers, opaque handles, structs)
 const PP = ref.refType(P);                   // pointer to a handle (ire_engine**, ire_job**, ire_strips**)
 const IP = ref.refType(ref.types.int);       // int*
-export const IRE_ABI_VERSION = 2;
+export const IRE_ABI_VERSION = 3;
 export function bindIre(libPath) {
   return ffi.Library(libPath, {
     ire_abi_version: ['int', []],
@@ -31,6 +31,9 @@ export function bindIre(libPath) {
     ire_preprocess_device: ['int', [P, P, 'int', 'int', 'int', 'int', P, 'int', 'int', P]],
     ire_submit: ['int', [P, P, 'int', 'int', 'int', P, PP]],
     ire_poll: ['int', [P, P, 'int', P, P, P]],
+    ire_job_release: ['int', [P, P]],
+    ire_affinity_plan: ['int', ['string', 'string', P, 'size_t', IP, IP, IP]],
+    ire_engine_affinity: ['int', [P, P, 'size_t', IP]],
     ire_restore_tiled_device: ['int', [P, P, 'int', 'int', 'int', P, P, P, P]],
     ire_strips_stats_bytes: ['size_t', ['int', 'int']],
     ire_strips_open: ['int', [P, 'int', 'int', 'int', 'int', 'int', P, PP]],

@@ -10,13 +10,19 @@
 // Buffer -> pinned staging) and waited for by this addon's OWN waiter threads (ire_poll with the job's
 // timeout, writing straight into the result Buffer), completed through a thread-safe function: the libuv
 // pool (4 threads shared with fs / dns / zlib / crypto) is never parked for the length of a GPU batch, and
-// a wedged engine rejects with ENGINE_TIMEOUT so the worker's retry -> DLQ path is reached.  libire.so is dlopen'ed at run time so the addon builds and loads on GPU-less hosts;
+// a wedged engine rejects with ENGINE_TIMEOUT so the worker's retry -> DLQ path is reached -- the timeout counts from SUBMIT (a deadline
+// stamped on the JS thread, not from the moment one of the four waiter threads picks the job up), and a job that timed out is given back to
+// the engine (ire_job_release) so that its handle and its place in the batch's staging slot are freed before the retry resubmits the image.
+// The waiter threads run on the CPUs the engine bound its own service threads to (ire_engine_affinity: the GPU's NUMA node).  libire.so is dlopen'ed at run time so the addon builds and loads on GPU-less hosts;
 // without a device ire_init fails and the rejection text contains "service unavailable".
 //
 // Build: g++ -O2 -shared -fPIC -I/usr/include/node ire_napi.cc -o ire_napi.node -ldl
 #include <dlfcn.h>
 #include <node_api.h>
+#include <pthread.h>
+#include <sched.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstring>
@@ -27,6 +33,7 @@
 #include <vector>
 
 #include "../../include/ire.h"
+#include "../csrc/affinity.hpp"      // parse_cpulist (host-only header)
 
 namespace {
 
@@ -41,6 +48,8 @@ struct Api {
     decltype(&ire_abi_version) abi_version = nullptr;
     decltype(&ire_submit) submit = nullptr;
     decltype(&ire_poll) poll = nullptr;
+    decltype(&ire_job_release) job_release = nullptr;
+    decltype(&ire_engine_affinity) engine_affinity = nullptr;
     decltype(&ire_preprocess_plan) preprocess_plan = nullptr;
     decltype(&ire_preprocess) preprocess = nullptr;
     decltype(&ire_get_stats) get_stats = nullptr;
@@ -52,11 +61,12 @@ bool load_api(const char* path, std::string* err) {
     g.so = dlopen(path, RTLD_NOW | RTLD_LOCAL);
     if (!g.so) { *err = std::string("service unavailable: cannot load ") + path + ": " + dlerror(); return false; }
 #define SYM(field, name) g.field = (decltype(g.field))dlsym(g.so, name); if (!g.field) { *err = "service unavailable: missing symbol " name; return false; }
+    SYM(abi_version, "ire_abi_version")
+    if (g.abi_version() != IRE_ABI_VERSION) { *err = "service unavailable: libire.so ABI version mismatch"; return false; }     // before the symbols a stale library lacks
     SYM(init, "ire_init") SYM(shutdown, "ire_shutdown") SYM(last_error, "ire_last_error") SYM(classify, "ire_classify")
-    SYM(restore, "ire_restore") SYM(fuse, "ire_fuse") SYM(abi_version, "ire_abi_version")
-    SYM(submit, "ire_submit") SYM(poll, "ire_poll") SYM(preprocess_plan, "ire_preprocess_plan") SYM(preprocess, "ire_preprocess")
+    SYM(restore, "ire_restore") SYM(fuse, "ire_fuse")
+    SYM(submit, "ire_submit") SYM(poll, "ire_poll") SYM(job_release, "ire_job_release") SYM(engine_affinity, "ire_engine_affinity") SYM(preprocess_plan, "ire_preprocess_plan") SYM(preprocess, "ire_preprocess")
     SYM(get_stats, "ire_get_stats") SYM(max_batch_for, "ire_max_batch_for")
-    if (g.abi_version() != IRE_ABI_VERSION) { *err = "service unavailable: libire.so ABI version mismatch"; return false; }
 #undef SYM
     return true;
 }
@@ -86,6 +96,7 @@ struct Job {
     // single-image restore through the batcher (waiter threads): the result Buffer is created up front on the JS thread and
     // ire_poll writes into it; the engine handle is referenced so that it cannot be finalized under a pending job
     int timeout_ms = 120000;
+    std::chrono::steady_clock::time_point deadline;      // submit time + timeout_ms
     uint8_t* out_ptr = nullptr;
     napi_ref out_ref = nullptr, eng_ref = nullptr;
 };
@@ -98,6 +109,7 @@ struct Waiters {
     napi_threadsafe_function tsfn = nullptr;
     int pending = 0;              // JS thread only: jobs handed to the waiters and not completed yet (keeps the tsfn referenced)
     bool started = false;
+    std::string cpulist;          // the engine's service-thread CPUs (ire_engine_affinity) at the time the waiters were started
 };
 Waiters* W = nullptr;             // leaked on purpose: detached threads may outlive static destruction
 constexpr int kWaiterThreads = 4;
@@ -187,6 +199,13 @@ void complete_ts(napi_env env, napi_value, void*, void* data) {
     if (--W->pending == 0) napi_unref_threadsafe_function(env, W->tsfn);      // idle: do not keep the event loop alive
 }
 void waiter_main() {
+    {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        int n = 0;
+        for (auto& r : ire::parse_cpulist(W->cpulist)) for (int c = r.first; c <= r.second; ++c) if (c >= 0 && c < CPU_SETSIZE) { CPU_SET(c, &set); ++n; }
+        if (n) (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+    }
     for (;;) {
         Job* j;
         {
@@ -195,18 +214,29 @@ void waiter_main() {
             j = W->q.front(); W->q.pop_front();
         }
         j->scores.resize(7);
-        j->status = g.poll(j->eng, j->queued, j->timeout_ms, j->out_ptr, j->scores.data(), &j->t);
+        // what is left of the job's timeout (stamped at submit: a job that queued behind three wedged polls does not get a fresh allowance)
+        const auto left = std::chrono::duration_cast<std::chrono::milliseconds>(j->deadline - std::chrono::steady_clock::now()).count();
+        j->status = g.poll(j->eng, j->queued, left > 0 ? (int)left : 0, j->out_ptr, j->scores.data(), &j->t);
         if (j->status != 0) j->err = g.last_error();          // thread-local: read on this thread
+        // IRE_ERR_TIMEOUT leaves the job pending by contract: nobody will poll it again (the promise rejects, the retry submits anew),
+        // so give it back -- its handle, its Job and its unread place in the batch's slot are freed now, not at the eighth slot's eviction
+        if (j->status == IRE_ERR_TIMEOUT) (void)g.job_release(j->eng, j->queued);
+        j->queued = nullptr;
         napi_call_threadsafe_function(W->tsfn, j, napi_tsfn_blocking);
     }
 }
-bool waiters_start(napi_env env) {
+bool waiters_start(napi_env env, ire_engine* eng) {
     if (!W) W = new Waiters();
     if (W->started) return true;
     napi_value name;
     napi_create_string_utf8(env, "ire-restore-done", NAPI_AUTO_LENGTH, &name);
     if (napi_create_threadsafe_function(env, nullptr, nullptr, name, 0, 1, nullptr, nullptr, nullptr, complete_ts, &W->tsfn) != napi_ok) return false;
     napi_unref_threadsafe_function(env, W->tsfn);
+    {
+        char buf[4096] = {0};
+        int32_t node = -1;
+        if (eng && g.engine_affinity && g.engine_affinity(eng, buf, sizeof(buf), &node) == 0) W->cpulist = buf;
+    }
     for (int i = 0; i < kWaiterThreads; ++i) std::thread(waiter_main).detach();
     W->started = true;
     return true;
@@ -265,7 +295,8 @@ napi_value submit(napi_env env, napi_callback_info info, Job::Kind kind) {
         // on the JS thread (ire_submit copies Buffer -> pinned staging: the only copy of the input), so that every in-flight
         // promise is in the batcher before anything waits; the waiter threads then ire_poll with the job's timeout
         if (argc > 7) { const int64_t tmo = get_i64(env, argv[7]); if (tmo > 0) j->timeout_ms = (int)(tmo > 0x7fffffff ? 0x7fffffff : tmo); }
-        int rc = waiters_start(env) ? 0 : 4;
+        j->deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(j->timeout_ms);
+        int rc = waiters_start(env, j->eng) ? 0 : 4;
         if (rc == 0) rc = g.submit(j->eng, (const uint8_t*)data, j->h, j->w, j->jpeg[0], j->has_scores ? j->scores.data() : nullptr, &j->queued);
         if (rc != 0) {
             napi_value msg, err, code;

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define IRE_ABI_VERSION 2
+#define IRE_ABI_VERSION 3   /* 3: ire_job_release, ire_affinity_plan, ire_engine_affinity, ire_profile_report; ire_profile_enable mode bits 8..; ire_config.flags checked */
 
 typedef enum ire_status {
     IRE_OK = 0,
@@ -149,10 +149,18 @@ typedef struct ire_job ire_job;
  * of this image returned (the job is then not classified again), or NULL => classify inside. */
 int ire_submit(ire_engine* e, const uint8_t* rgb, int h, int w, int is_jpeg, const double* scores, ire_job** job_out);
 /* Wait up to timeout_ms (<0: forever) for the job; on IRE_OK out_rgb (h*w*3), scores_out (7, may
- * be NULL) and t (may be NULL) are filled and the job is released.  IRE_ERR_TIMEOUT leaves the
- * job pending. */
+ * be NULL) and t (may be NULL) are filled and the job is released; any other status but
+ * IRE_ERR_TIMEOUT releases it too.  IRE_ERR_TIMEOUT leaves the job pending and the handle valid:
+ * poll again, or give the job up with ire_job_release.  One thread at a time per handle. */
 int ire_poll(ire_engine* e, ire_job* job, int timeout_ms, uint8_t* out_rgb, double* scores_out,
              ire_timings* t);
+/* Give up a job without fetching its result -- the caller's promise was rejected on a timeout and
+ * the retry policy (server-node/src/utils/retry.js:12-47, 3 attempts) will submit the image anew:
+ * frees the handle and whatever only it kept alive (its place among a finished batch's unread
+ * results, so the staging slot can cycle; its queued pixels if it never reached a batch).  A job
+ * already gathered into a batch is still computed with it.  e == NULL after ire_shutdown: frees
+ * the handle only.  job == NULL: no-op. */
+int ire_job_release(ire_engine* e, ire_job* job);
 
 /* ---- cfg 4: one large image restored as row strips (imagePreprocess.js:4 caps uploads at 2048 px) ----
  * The image is cut into nstrips equal row strips; every layer runs strip by strip, the boundary rows of every tensor a 3x3
@@ -188,6 +196,15 @@ int ire_strips_pack_halo(ire_strips* s, int k, uint8_t* d_send_up, uint8_t* d_se
 int ire_strips_unpack_halo(ire_strips* s, int k, const uint8_t* d_recv_up, const uint8_t* d_recv_down, void* stream);
 /* d_out_rows: nlocal*rows_per_strip x w x 3 */
 int ire_strips_get_output(ire_strips* s, uint8_t* d_out_rows, void* stream);
+
+/* ---- host feeding at 8 ranks per host (restorator.js:198-211: one independent job per image) ----
+ * The engine's service threads (batch launcher, completer) run on the NUMA node of their GPU, on the share of that node's
+ * CPUs that falls to this GPU among the node's GPUs (csrc/affinity.hpp); IRE_CPU_AFFINITY=off | <cpulist> overrides.
+ * ire_affinity_plan is pure host arithmetic over sysfs (no GPU): sysfs_root NULL = "/sys"; pci_bdf as hipDeviceGetPCIBusId
+ * prints it ("0000:c1:00.0"); cpulist_out "" when the node is unknown.  ire_engine_affinity: what engine e applied. */
+int ire_affinity_plan(const char* sysfs_root, const char* pci_bdf, char* cpulist_out, size_t cap, int32_t* numa_node_out,
+                      int32_t* slot_out, int32_t* nslots_out);
+int ire_engine_affinity(ire_engine* e, char* cpulist_out, size_t cap, int32_t* numa_node_out);
 
 /* ---- service gauges (getHealthStatus + /health/ready dependency entry: restorator.js:289-314, healthRouter.js:80-117) ---- */
 typedef struct ire_engine_stats {

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(lib, name), name
     hdr = int(re.search(r"#define IRE_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "ire.h")).read()).group(1))
-    assert _lib.load().ire_abi_version() == hdr == 2
+    assert _lib.load().ire_abi_version() == hdr == _lib.IRE_ABI_VERSION == 3
 
 
 def test_no_cpu_fallback_without_device():

@@ -93,7 +93,7 @@ def test_seeded_random_shapes_vs_fp32_oracle(engine, weights0):
 
 @pytest.mark.parametrize("env", [{"IRE_W4": "0"}, {"IRE_W4_WAVES": "4", "IRE_ACT_SPLIT_MINC": "128"}, {"IRE_W4_WAVES": "4"}, {"IRE_CONV_V1": "1"}, {"IRE_UP_RB_MINC": "64"},
                                  {"IRE_ACT_SPLIT_MINC": "64"}, {"IRE_ACT_SPLIT_MINC": "128"}, {"IRE_UP_SUBPIX": "0"}, {"IRE_UP_FUSE": "0"}, {"IRE_GN_FOLD": "0"}, {"IRE_PC": "0"}, {"IRE_PC": "1"}, {"IRE_PC": "7"}, {"IRE_PC": "3"}, {"IRE_PC": "0", "IRE_GN_FOLD": "0"}, {"IRE_DOWN_RB": "0", "IRE_HEAD_RB": "0"}, {"IRE_STEM_RB": "0"},
-                                 {"IRE_W4_FUSED_MINC": "100000", "IRE_ACT_SPLIT_MINC": "256"}, {"IRE_W4_FUSED_MINC": "100000"}, {"IRE_W4_SPLIT": "0"}])
+                                 {"IRE_W4_FUSED_MINC": "100000", "IRE_ACT_SPLIT_MINC": "256"}, {"IRE_W4_FUSED_MINC": "100000"}, {"IRE_W4_SPLIT": "0"}, {"IRE_PK": "0"}])
 def test_alternate_kernel_schedules_agree(engine, weights0, env, monkeypatch):
     """Every A/B switch of the engine (conv_rb instead of conv_w4 at C >= 128, the 4-wave conv_w4, the v1 conv schedule, the
     v1 `up` kernel, the separate activation pass from C = 64, nearest x2 + 3x3 instead of the sub-pixel `up` convolution) computes the same network: each meets the oracle bound, and
@@ -113,6 +113,24 @@ def test_alternate_kernel_schedules_agree(engine, weights0, env, monkeypatch):
     _assert_close(alt, onet.restore(imgs, sc, weights0))
     d = np.abs(alt.astype(np.int32) - base.astype(np.int32))
     assert d.max() <= 2 and np.mean(d > 0) < 0.2, (int(d.max()), float(np.mean(d > 0)))
+
+
+def test_producer_consumer_c128_equals_conv_w4_bit_for_bit(engine, weights0, monkeypatch):
+    """conv_pk.hip (the C >= 128 ResBlock convs as producer / consumer workgroups, the default since round 4) keeps conv_w4's
+    tiles, weight slabs, accumulation order, epilogue arithmetic and partials layout: the two schedules must deliver EQUAL bytes --
+    on a batch whose C = 128 / 256 levels have several ragged tiles per image and whose workgroups cross image boundaries."""
+    from image_restoration_platform_amd.engine import Engine
+    imgs = synth.batch(3, 200, 328, start=21)          # level 2: 50 x 82 (4 x 3 tiles, ragged), level 3: 25 x 41 (2 x 2 tiles, ragged)
+    sc = _scores(imgs)
+    base = engine.restore(imgs, scores=sc)
+    _assert_close(base, onet.restore(imgs, sc, weights0))
+    monkeypatch.setenv("IRE_PK", "0")
+    alt_engine = Engine(device_index=0, max_batch=8)
+    try:
+        alt = alt_engine.restore(imgs, scores=sc)
+    finally:
+        alt_engine.close()
+    assert np.array_equal(alt, base), int(np.abs(alt.astype(np.int32) - base.astype(np.int32)).max())
 
 
 @pytest.mark.parametrize("n,h,w", [(12, 32, 48), (20, 16, 32)])
@@ -326,6 +344,92 @@ def test_async_batcher_submit_poll(engine):
     for j, (out, scores, t) in enumerate(outs):
         assert np.array_equal(out, ref2[j])
     assert np.array_equal(outs[0][1], other[0]) and np.array_equal(outs[1][1], sc[1])
+
+
+def test_batcher_four_threads_two_shapes_out_of_order_abandon_and_shutdown():
+    """The slot state machine of csrc/batcher.hpp on the GPU (its sanitizer runs are tests/test_batcher_native.py): 4 native threads
+    (ctypes releases the GIL: the submits' staging copies and the polls really overlap) x 16 jobs, two shapes interleaved, all 64
+    submitted before the first poll with max_batch 2 (8 slots hold 16: overflow queue, launcher-side staging, eviction of unread
+    DONE slots), polls in random order with 0 / 1 ms timeouts retried, one thread giving jobs up with ire_job_release (pending and
+    timed-out ones), then an engine shut down with jobs pending whose handles are freed afterwards (e == NULL).  Every delivered
+    result equals ire_restore of the same image with the same scores; queueDepth returns to 0.
+    Reference: restorator.js:181-236 (in-flight promises), utils/retry.js:12-47 (a timed-out attempt is abandoned and retried)."""
+    import threading
+    from image_restoration_platform_amd.engine import Engine, EngineError
+    eng = Engine(max_batch=2)
+    try:
+        shapes = [(64, 64), (48, 80)]
+        imgs = {s: synth.batch(32, s[0], s[1], start=100 + 7 * k) for k, s in enumerate(shapes)}
+        sc = {s: np.concatenate([eng.classify(imgs[s][i:i + 2], True)[0] for i in range(0, 32, 2)]) for s in shapes}
+        given = {s: np.clip(sc[s] + 0.0625, 0, 1) for s in shapes}
+        # serial reference: two images at a time through ire_restore; odd jobs bring scores, even jobs are classified inside
+        use = {s: np.stack([given[s][i] if i & 1 else sc[s][i] for i in range(32)]) for s in shapes}
+        ref = {s: np.concatenate([eng.restore(imgs[s][i:i + 2], scores=use[s][i:i + 2]) for i in range(0, 32, 2)]) for s in shapes}
+        errors, delivered, released = [], [0], [0]
+        lock = threading.Lock()
+        barrier = threading.Barrier(4)
+
+        def worker(t):
+            try:
+                rng = np.random.default_rng(1000 + t)
+                mine = []
+                for k in range(16):
+                    s = shapes[(k + t) & 1]
+                    i = (t * 16 + k) % 32
+                    mine.append((s, i, eng.submit(imgs[s][i], is_jpeg=True, scores=given[s][i] if i & 1 else None)))
+                barrier.wait()                          # all 64 jobs are in before anybody polls
+                order = list(rng.permutation(16))
+                n_rel = 0
+                while order:
+                    for pos in list(order):
+                        s, i, job = mine[pos]
+                        if t == 3 and n_rel < 5 and pos % 3 == 0:        # given up without a poll
+                            eng.release(job); order.remove(pos); n_rel += 1
+                            continue
+                        try:
+                            out, scores, _ = eng.poll(job, timeout_ms=int(rng.integers(0, 2)))
+                        except EngineError as e:
+                            assert e.status == 2 and "timeout" in e.message, (e.status, e.message)
+                            if t == 3 and n_rel < 8 and rng.integers(0, 3) == 0:    # a timed-out job given up
+                                eng.release(job); order.remove(pos); n_rel += 1
+                            continue
+                        assert np.array_equal(out, ref[s][i]), (t, pos, s, i)
+                        assert np.array_equal(scores, use[s][i])
+                        order.remove(pos)
+                        with lock:
+                            delivered[0] += 1
+                with lock:
+                    released[0] += n_rel
+            except BaseException as e:                   # noqa: BLE001 -- reported by the main thread
+                errors.append(repr(e))
+                try:
+                    barrier.abort()
+                except Exception:
+                    pass
+
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+        [x.start() for x in th]
+        [x.join(300) for x in th]
+        assert not errors, errors
+        assert delivered[0] + released[0] == 64 and released[0] >= 5
+        import time
+        for _ in range(200):
+            if eng.stats()["queueDepth"] == 0:
+                break
+            time.sleep(0.005)
+        assert eng.stats()["queueDepth"] == 0
+        # a steady closed loop still works after all that (slots recycled, nothing wedged)
+        jobs = [eng.submit(imgs[shapes[0]][i]) for i in range(6)]
+        for i, job in enumerate(jobs):
+            out, _, _ = eng.poll(job, timeout_ms=60000)
+            assert np.array_equal(out, eng.restore(imgs[shapes[0]][i:i + 1], scores=sc[shapes[0]][i:i + 1])[0])
+        # shut down with jobs pending: gathered, in flight, overflowing; the handles are freed without an engine
+        pending = [eng.submit(imgs[shapes[k & 1]][k]) for k in range(24)]
+    finally:
+        eng.close()
+    from image_restoration_platform_amd import _lib
+    for handle, _, _ in pending:
+        assert _lib.load().ire_job_release(None, handle) == 0
 
 
 def test_error_paths(engine):
