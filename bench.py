@@ -53,6 +53,7 @@ def parse_args(argv=None):
     ap.add_argument("--strips", type=int, default=8, help="tiled: row strips per image on ONE GPU (virtual ranks); with N > 1 ranks each rank owns one strip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-buffer (PCIe-inclusive) sub-record measured after the timed region")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the BASELINE cfg 1 (512x512 bs 8) sub-record measured after the timed region")
     ap.add_argument("--no-profile", action="store_true", help="skip the in-engine HIP-event kernel timing")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel family (more events, ~5 %% slower)")
     ap.add_argument("--profile-every", type=int, default=4, help="time the dominant family's launches on every N-th timed step (an event record is a packet "
@@ -150,18 +151,53 @@ def host_path(eng, size, batch, jobs=64):
     out = {}
     for inflight in (8, 16):
         b0 = eng.stats()["batches"]
-        t0 = time.perf_counter()
-        q = collections.deque()
-        for i in range(jobs):
-            if len(q) == inflight:
-                eng.poll(q.popleft())
-            q.append(eng.submit(x[i % batch]))
-        while q:
-            eng.poll(q.popleft())
-        dt = time.perf_counter() - t0
+        dt = closed_loop(eng, x, jobs, inflight)
         out["submit_poll_%d_in_flight" % inflight] = {"images_per_sec": jobs / dt, "engine_batches": eng.stats()["batches"] - b0, "jobs": jobs}
     out["ire_restore_host_batches"] = {"images_per_sec": host_batch, "batch": batch}
+    cpus, node = eng.affinity()
+    out["service_thread_affinity"] = {"cpulist": cpus, "numa_node": node}
     return out
+
+
+def closed_loop(eng, x, jobs, inflight):
+    """`jobs` single-image jobs from ONE thread, `inflight` outstanding: poll the oldest, submit the next.  Seconds."""
+    import collections
+    t0 = time.perf_counter()
+    q = collections.deque()
+    for i in range(jobs):
+        if len(q) == inflight:
+            eng.poll(q.popleft())
+        q.append(eng.submit(x[i % len(x)]))
+    while q:
+        eng.poll(q.popleft())
+    return time.perf_counter() - t0
+
+
+def host_path_ranks(ctx, eng, size, batch, jobs=64, inflight=16):
+    """N > 1: EVERY rank feeds its GPU from host memory at once -- one submit thread per GPU, 16 single-image jobs in flight, the
+    batcher's pinned staging and its service threads on the GPU's NUMA node (csrc/affinity.hpp) -- between two barriers; the time
+    is the MAX over ranks like the step time (the 8-GPU target is about host feeding; restorator.js:198-211).
+    Returns (on rank 0) the whole-host rate and each rank's own rate and CPU plan."""
+    from image_restoration_platform_amd import synth
+    x = synth.batch(batch, size, size, start=ctx.rank * batch)
+    for j in [eng.submit(x[i % batch]) for i in range(2 * batch)]:
+        eng.poll(j)
+    ctx.sync()
+    if ctx.world > 1:
+        ctx.dist.barrier()
+    dt = closed_loop(eng, x, jobs, inflight)
+    cpus, node = eng.affinity()
+    mine = {"rank": ctx.rank, "images_per_sec": jobs / dt, "seconds": dt, "cpulist": cpus, "numa_node": node}
+    rows = [mine]
+    if ctx.world > 1:
+        rows = [None] * ctx.world
+        ctx.dist.all_gather_object(rows, mine)
+    if ctx.rank != 0:
+        return None
+    worst = max(r["seconds"] for r in rows)
+    return {"jobs_per_rank": jobs, "in_flight_per_rank": inflight, "images_per_sec": ctx.world * jobs / worst, "seconds_max_over_ranks": worst,
+            "per_rank": rows, "pcie_bytes_per_image": 2 * 3 * size * size,
+            "note": "host buffers -> pinned staging -> H2D -> restore -> D2H -> host buffers on every rank at once; never the bench `value`"}
 
 
 def per_level_roofline(groups, steps, counters=None):
@@ -262,13 +298,30 @@ def line(ctx, metric, value, dt, dtype, config, extra=None):
 # workloads
 # ------------------------------------------------------------------------------------------------------
 def run_stub(ctx):
-    """Test stand-in for the GPU step (tests/test_distributed.py): the same sharding, timing and reporting code over gloo."""
+    """Test stand-in for the GPU step (tests/test_distributed.py): the same sharding, timing and reporting code over gloo.
+    IRE_STUB_SYSFS / IRE_STUB_BDFS (a fabricated sysfs tree and one PCI address per rank): every rank asks libire.so for the CPU plan
+    of ITS GPU (ire_affinity_plan: host arithmetic, no device) and rank 0 reports all of them, as host_path_ranks does on a node."""
     a = ctx.args
     lo, hi = ctx.sharding.shard_range(a.batch * ctx.world, ctx.rank, ctx.world)
     dt = ctx.timed(lambda i: time.sleep(0.002 * (ctx.rank + 1)))
+    plans = None
+    if os.environ.get("IRE_STUB_SYSFS"):
+        import ctypes
+        from image_restoration_platform_amd import _lib
+        lib = _lib.load()
+        bdf = os.environ["IRE_STUB_BDFS"].split(",")[ctx.rank]
+        buf = ctypes.create_string_buffer(1024)
+        node, slot, nslots = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        assert lib.ire_affinity_plan(os.environ["IRE_STUB_SYSFS"].encode(), bdf.encode(), buf, len(buf), ctypes.byref(node), ctypes.byref(slot), ctypes.byref(nslots)) == 0
+        mine = {"rank": ctx.rank, "bdf": bdf, "cpulist": buf.value.decode(), "numa_node": node.value, "slot": slot.value, "nslots": nslots.value}
+        plans = [mine]
+        if ctx.world > 1:
+            plans = [None] * ctx.world
+            ctx.dist.all_gather_object(plans, mine)
     if ctx.rank == 0:
         print(json.dumps(line(ctx, "stub images/sec", ctx.world * a.steps * a.batch / dt, dt, "u8",
-                              {"workload": "stub", "shard_of_rank0": [lo, hi], "global_batch": a.batch * ctx.world})))
+                              {"workload": "stub", "shard_of_rank0": [lo, hi], "global_batch": a.batch * ctx.world},
+                              {"host_path": {"per_rank": plans}} if plans else None)))
 
 
 def run_restore(ctx, eng):
@@ -304,6 +357,7 @@ def run_restore(ctx, eng):
         eng.profile_enable(0)
         prof = {f: eng.profile_query(f) for f in ("conv3x3", "conv1x1", "stem", "head", "classifier", "gn_finalize", "all")}
         report = eng.profile_report()
+    hp_ranks = host_path_ranks(ctx, eng, S, B) if (ctx.world > 1 and not a.no_host_path) else None      # every rank takes part
     if ctx.rank != 0:
         return
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
@@ -318,7 +372,7 @@ def run_restore(ctx, eng):
         # HBM bytes per launch from PMC counters cannot be collected from inside this process; they come from the committed
         # rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled per MI355X_MICROARCH.md), valid for 1024x1024 bs=8 only.
         traffic, traffic_src, tr = None, None, None
-        for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             tj = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tj) and S == 1024 and B == 8:
                 with open(tj) as f:
@@ -347,9 +401,43 @@ def run_restore(ctx, eng):
         res["whole_net_mfma_frac"] = (f3 + f1) * B * a.steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS
     if ctx.world == 1 and not a.no_host_path:
         res["host_path"] = host_path(eng, S, B)
+    elif hp_ranks is not None:
+        res["host_path"] = {"all_ranks_closed_loop": hp_ranks}
+    if ctx.world == 1 and not a.no_secondary and S == 1024:
+        res["secondary"] = {"cfg1_512": secondary_512(ctx, eng, B)}
     if ctx.world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(S)
     print(json.dumps(res))
+
+
+def secondary_512(ctx, eng, B, steps=12, warmup=3):
+    """BASELINE.json cfg 1 (512x512 bs 8, 1 GPU) as a sub-record of the default line, measured AFTER the timed region (~0.1 s): the
+    same step at the other named shape, inputs resident in HBM, the conv3x3 family HIP-event timed on every step."""
+    from image_restoration_platform_amd import synth, weights
+    torch = ctx.torch
+    S = 512
+    x = torch.from_numpy(synth.batch(B, S, S)).to(ctx.dev)
+    jpeg = torch.ones(B, dtype=torch.uint8, device=ctx.dev)
+    out = torch.empty_like(x)
+    for _ in range(warmup):
+        eng.restore_tensor(x, out, scores=None, is_jpeg_u8=jpeg)
+    torch.cuda.synchronize()
+    eng.profile_reset()
+    eng.profile_enable(2 | (1 << 8))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.restore_tensor(x, out, scores=None, is_jpeg_u8=jpeg)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng.profile_enable(0)
+    c3 = eng.profile_query("conv3x3")
+    rep = per_level_roofline(eng.profile_report(), steps)
+    f3, f1 = weights.conv_flops(S, S)
+    ach = c3["flops"] / (c3["ms"] * 1e-3) / 1e12 if c3["ms"] > 0 else 0.0
+    return {"workload": "512x512 RGB u8, batch %d, 1 GPU (BASELINE cfg 1)" % B, "images_per_sec": steps * B / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
+            "conv3x3_family": {"achieved": ach, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "ms_per_step": c3["ms"] / steps,
+                               "frac_of_per_layer_roofline": rep["frac_of_per_layer_roofline"]},
+            "per_level": rep["per_level"], "whole_net_mfma_frac": (f3 + f1) * B * steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS}
 
 
 def run_classify(ctx, eng):

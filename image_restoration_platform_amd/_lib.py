@@ -6,6 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IRE_LIB") or os.path.join(HERE, "lib", "libire.so")   # IRE_LIB: A/B another build of the same ABI (tools/ab_bench.sh)
 
 IRE_OK, IRE_ERR_INVALID_INPUT, IRE_ERR_TIMEOUT, IRE_ERR_UNAVAILABLE, IRE_ERR_INTERNAL = range(5)
+IRE_FLAG_RESULT_PNG_BASE64 = 1
 IRE_ABI_VERSION = 3      # include/ire.h; load() refuses a library of another version (tests/test_abi.py cross-checks the three copies)
 
 
@@ -49,6 +50,9 @@ SYMBOLS = {
     "ire_preprocess_plan": (_i, [_i, _i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "ire_preprocess": (_i, [_vp, _u8p, _i, _i, _i, _i, _u8p, _i, _i]),
     "ire_preprocess_device": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    "ire_png_base64_bytes": (ctypes.c_size_t, [_i, _i]),
+    "ire_encode_png_base64_device": (_i, [_vp, _vp, _i, _i, _i, _vp, ctypes.c_size_t, _vp]),
+    "ire_encode_png_base64": (_i, [_vp, _u8p, _i, _i, _i, _u8p, ctypes.c_size_t]),
     "ire_submit": (_i, [_vp, _u8p, _i, _i, _i, _vp, ctypes.POINTER(_vp)]),
     "ire_restore_tiled_device": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ire_strips_stats_bytes": (ctypes.c_size_t, [_i, _i]),

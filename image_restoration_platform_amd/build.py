@@ -36,11 +36,13 @@ SOURCES = [
      (["-DC3_TEPI64=" + os.environ["C3_TEPI64"]] if os.environ.get("C3_TEPI64") else []) +
      (["-DIRE_LD_ONCE32=" + os.environ["IRE_LD_ONCE32"]] if os.environ.get("IRE_LD_ONCE32") else []) +
      (["-DC3_PROD8=" + os.environ["C3_PROD8"]] if os.environ.get("C3_PROD8") else []) +
-     (["-DIRE_PC_TICKS"] if os.environ.get("IRE_RB_ABLATE") == "2" else [])),
-    ("conv_pk.hip", (["-DPK_ABL=" + os.environ["PK_ABL"]] if os.environ.get("PK_ABL") else [])),
+     (["-DIRE_PC_TICKS"] if os.environ.get("IRE_RB_ABLATE") == "2" else []) + (["-DIRE_W4_TL"] if os.environ.get("IRE_W4_TL") else [])),
+    ("conv_pk.hip", (["-DPK_ABL=" + os.environ["PK_ABL"]] if os.environ.get("PK_ABL") else []) +
+     (["-DPK_TICKS"] if os.environ.get("PK_TICKS") else []) + (["-DIRE_W4_TL"] if os.environ.get("IRE_W4_TL") else []) + os.environ.get("PK_DEFS", "").split()),
     ("gn.hip", []),
     ("fusion.hip", (["-DFUSE_FL=" + os.environ["FUSE_FL"]] if os.environ.get("FUSE_FL") else [])),
     ("preprocess.hip", []),
+    ("encode.hip", []),
     ("engine.cpp", []),
     ("strips.cpp", []),
     ("api.cpp", []),

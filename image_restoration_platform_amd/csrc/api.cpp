@@ -14,6 +14,7 @@
 
 #include "affinity.hpp"
 #include "batcher.hpp"
+#include "encode.hpp"
 #include "engine.hpp"
 #include "fusion.hpp"
 #include "strips.hpp"
@@ -43,8 +44,12 @@ struct DeviceGuard {       // staging is allocated on first use of a shape, poss
 };
 
 struct HipSlot {
-    uint8_t *d_in = nullptr, *d_out = nullptr, *d_jp = nullptr;
-    hipEvent_t ev_in = nullptr, ev_c0 = nullptr, ev_c1 = nullptr, ev_out = nullptr;
+    uint8_t *d_in = nullptr, *d_out = nullptr, *d_jp = nullptr, *d_txt = nullptr;      // d_txt: IRE_FLAG_RESULT_PNG_BASE64, the results' text
+    hipEvent_t ev_in = nullptr, ev_c0 = nullptr, ev_c1 = nullptr, ev_cw = nullptr, ev_out = nullptr;
+    // ev_c1 and ev_cw mark the same point (the batch's compute is done): the launcher QUERIES ev_c1 under the batcher's lock while
+    // the completer SLEEPS on ev_cw -- hipEventSynchronize holds the event's own lock for as long as it waits, so a query of the
+    // same event from another thread blocks until the batch is done (measured: with one event for both, every submitter stalled
+    // behind the launcher for a whole batch and a 16-deep closed loop fell to batches of one, 464 img/s)
 };
 
 // CPU set of this engine's service threads (affinity.hpp): IRE_CPU_AFFINITY = "off" | a cpulist overrides the sysfs plan
@@ -95,6 +100,8 @@ struct HipBatchBackend {
         if (os) { (void)hipStreamSynchronize(os); (void)hipStreamDestroy(os); }
     }
     int max_batch() const { return E.max_batch(); }
+    bool text() const { return (E.flags() & IRE_FLAG_RESULT_PNG_BASE64) != 0; }
+    size_t out_bytes(int h, int w) const { return text() ? png_base64_chars(h, w) : (size_t)h * w * 3; }
     void start() {
         DeviceGuard g(device);
         if (!cs) IRE_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
@@ -107,7 +114,7 @@ struct HipBatchBackend {
         if (b.fixed && bytes <= b.cap) return;
         DeviceGuard g(device);
         HipSlot nh;
-        uint8_t *pj = nullptr, *pi = nullptr, *po = nullptr, *di = nullptr, *dout = nullptr;
+        uint8_t *pj = nullptr, *pi = nullptr, *po = nullptr, *di = nullptr, *dout = nullptr, *dtxt = nullptr;
         double *ps = nullptr, *psi = nullptr;
         const bool want_fixed = !b.fixed, want_img = bytes > b.cap;
         try {
@@ -115,6 +122,7 @@ struct HipBatchBackend {
                 IRE_HIP(hipEventCreateWithFlags(&nh.ev_in, hipEventDisableTiming));
                 IRE_HIP(hipEventCreate(&nh.ev_c0));
                 IRE_HIP(hipEventCreate(&nh.ev_c1));
+                IRE_HIP(hipEventCreateWithFlags(&nh.ev_cw, hipEventDisableTiming));
                 IRE_HIP(hipEventCreateWithFlags(&nh.ev_out, hipEventDisableTiming));
                 IRE_HIP(hipHostMalloc((void**)&pj, (size_t)mb));
                 IRE_HIP(hipHostMalloc((void**)&ps, sizeof(double) * 7 * (size_t)mb));
@@ -126,11 +134,13 @@ struct HipBatchBackend {
                 IRE_HIP(hipHostMalloc((void**)&po, bytes));
                 IRE_HIP(hipMalloc((void**)&di, bytes));
                 IRE_HIP(hipMalloc((void**)&dout, bytes));
+                if (text()) IRE_HIP(hipMalloc((void**)&dtxt, bytes + 256 * (size_t)mb));
             }
         } catch (...) {
             if (nh.ev_in) (void)hipEventDestroy(nh.ev_in);
             if (nh.ev_c0) (void)hipEventDestroy(nh.ev_c0);
             if (nh.ev_c1) (void)hipEventDestroy(nh.ev_c1);
+            if (nh.ev_cw) (void)hipEventDestroy(nh.ev_cw);
             if (nh.ev_out) (void)hipEventDestroy(nh.ev_out);
             if (pj) (void)hipHostFree(pj);
             if (ps) (void)hipHostFree(ps);
@@ -140,17 +150,18 @@ struct HipBatchBackend {
             if (po) (void)hipHostFree(po);
             if (di) (void)hipFree(di);
             if (dout) (void)hipFree(dout);
+            if (dtxt) (void)hipFree(dtxt);
             throw;
         }
         HipSlot* hs = static_cast<HipSlot*>(b.impl);
         if (!hs) { hs = new HipSlot(); b.impl = hs; }
         if (want_fixed) {
-            hs->ev_in = nh.ev_in; hs->ev_c0 = nh.ev_c0; hs->ev_c1 = nh.ev_c1; hs->ev_out = nh.ev_out; hs->d_jp = nh.d_jp;
+            hs->ev_in = nh.ev_in; hs->ev_c0 = nh.ev_c0; hs->ev_c1 = nh.ev_c1; hs->ev_cw = nh.ev_cw; hs->ev_out = nh.ev_out; hs->d_jp = nh.d_jp;
             b.pin_jp = pj; b.pin_sc = ps; b.pin_sc_in = psi; b.fixed = true;
         }
         if (want_img) {
-            if (b.pin_in) { (void)hipHostFree(b.pin_in); (void)hipHostFree(b.pin_out); (void)hipFree(hs->d_in); (void)hipFree(hs->d_out); }
-            b.pin_in = pi; b.pin_out = po; hs->d_in = di; hs->d_out = dout; b.cap = bytes;
+            if (b.pin_in) { (void)hipHostFree(b.pin_in); (void)hipHostFree(b.pin_out); (void)hipFree(hs->d_in); (void)hipFree(hs->d_out); if (hs->d_txt) (void)hipFree(hs->d_txt); }
+            b.pin_in = pi; b.pin_out = po; hs->d_in = di; hs->d_out = dout; hs->d_txt = dtxt; b.cap = bytes;
         }
     }
     void release(SlotBufs& b) noexcept {
@@ -159,8 +170,8 @@ struct HipBatchBackend {
         if (b.pin_in) { (void)hipHostFree(b.pin_in); (void)hipHostFree(b.pin_out); }
         if (b.fixed) { (void)hipHostFree(b.pin_jp); (void)hipHostFree(b.pin_sc); (void)hipHostFree(b.pin_sc_in); }
         if (hs) {
-            if (hs->d_in) { (void)hipFree(hs->d_in); (void)hipFree(hs->d_out); }
-            if (hs->ev_in) { (void)hipEventDestroy(hs->ev_in); (void)hipEventDestroy(hs->ev_c0); (void)hipEventDestroy(hs->ev_c1); (void)hipEventDestroy(hs->ev_out); (void)hipFree(hs->d_jp); }
+            if (hs->d_in) { (void)hipFree(hs->d_in); (void)hipFree(hs->d_out); if (hs->d_txt) (void)hipFree(hs->d_txt); }
+            if (hs->ev_in) { (void)hipEventDestroy(hs->ev_in); (void)hipEventDestroy(hs->ev_c0); (void)hipEventDestroy(hs->ev_c1); (void)hipEventDestroy(hs->ev_cw); (void)hipEventDestroy(hs->ev_out); (void)hipFree(hs->d_jp); }
             delete hs;
         }
         b = SlotBufs{};
@@ -180,14 +191,19 @@ struct HipBatchBackend {
             IRE_HIP(hipEventRecord(hs.ev_c0, ms));
             E.restore_device_mixed(hs.d_in, n, h, w, b.pin_sc_in, has_sc, hs.d_jp, hs.d_out, ms);   // classifies the jobs that brought no scores
             IRE_HIP(hipMemcpyAsync(b.pin_sc, E.scores_device(), sizeof(double) * 7 * n, hipMemcpyDeviceToHost, ms));
+            if (text()) E.encode_png_base64_device(hs.d_out, n, h, w, hs.d_txt, (out_bytes(h, w) + 255) / 256 * 256, ms);     // the results leave the device as text
             IRE_HIP(hipEventRecord(hs.ev_c1, ms));
+            IRE_HIP(hipEventRecord(hs.ev_cw, ms));
         });
         IRE_HIP(hipStreamWaitEvent(os, hs.ev_c1, 0));
-        IRE_HIP(hipMemcpyAsync(b.pin_out, hs.d_out, ib * n, hipMemcpyDeviceToHost, os));
+        if (text()) {
+            const size_t ob = out_bytes(h, w), st = (ob + 255) / 256 * 256;
+            for (int i = 0; i < n; ++i) IRE_HIP(hipMemcpyAsync(b.pin_out + ob * i, hs.d_txt + st * i, ob, hipMemcpyDeviceToHost, os));
+        } else IRE_HIP(hipMemcpyAsync(b.pin_out, hs.d_out, ib * n, hipMemcpyDeviceToHost, os));
         IRE_HIP(hipEventRecord(hs.ev_out, os));
     }
     bool computing(SlotBufs& b) noexcept { return hipEventQuery(static_cast<HipSlot*>(b.impl)->ev_c1) == hipErrorNotReady; }
-    void wait_compute(SlotBufs& b) noexcept { (void)hipEventSynchronize(static_cast<HipSlot*>(b.impl)->ev_c1); }
+    void wait_compute(SlotBufs& b) noexcept { (void)hipEventSynchronize(static_cast<HipSlot*>(b.impl)->ev_cw); }
     void wait_done(SlotBufs& b, ire_timings& t) {
         HipSlot& hs = *static_cast<HipSlot*>(b.impl);
         const hipError_t rc = hipEventSynchronize(hs.ev_out);
@@ -387,6 +403,22 @@ int ire_preprocess_device(ire_engine* e, const uint8_t* d_rgb, int h, int w, int
     return guarded([&] {
         Engine& E = eng(e);
         on_stream(E, (hipStream_t)stream, [&] { E.preprocess_device(d_rgb, h, w, orientation, max_dim, d_out_rgb, out_h, out_w, (hipStream_t)stream); });
+    });
+}
+
+size_t ire_png_base64_bytes(int h, int w) { return (h >= 1 && w >= 8 && w % 8 == 0 && h <= 16384 && w <= 16384) ? png_base64_chars(h, w) : 0; }
+
+int ire_encode_png_base64_device(ire_engine* e, const uint8_t* d_rgb, int n, int h, int w, uint8_t* d_chars, size_t stride_bytes, void* stream) {
+    return guarded([&] {
+        Engine& E = eng(e);
+        on_stream(E, (hipStream_t)stream, [&] { E.encode_png_base64_device(d_rgb, n, h, w, d_chars, stride_bytes, (hipStream_t)stream); });
+    });
+}
+
+int ire_encode_png_base64(ire_engine* e, const uint8_t* rgb, int n, int h, int w, uint8_t* chars, size_t stride_bytes) {
+    return guarded([&] {
+        Engine& E = eng(e);
+        on_stream(E, E.main_stream(), [&] { E.encode_png_base64_host(rgb, n, h, w, chars, stride_bytes); });
     });
 }
 

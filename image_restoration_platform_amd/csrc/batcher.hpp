@@ -29,6 +29,8 @@
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <exception>
@@ -87,6 +89,7 @@ struct BatchSlot {
 
 // Backend concept (HipBatchBackend in api.cpp; StubBackend in tests/native/batcher_stress.cpp):
 //   int  max_batch() const;
+//   size_t out_bytes(int h, int w) const;                      bytes of one job's result (h * w * 3 pixels, or the text of an encoded image)
 //   void start();                                              first submit, batcher lock held: streams
 //   void thread_enter(const char* role);                       at the top of a service thread: device, CPU affinity
 //   void reserve(SlotBufs&, size_t bytes, int max_batch);      grow to `bytes` per direction; STRONG guarantee: on a throw the SlotBufs is as before
@@ -101,7 +104,7 @@ template <class Backend>
 class Batcher {
   public:
     using clk = std::chrono::steady_clock;
-    explicit Batcher(Backend& be) : be_(be) {}
+    explicit Batcher(Backend& be) : be_(be) { const char* t = std::getenv("IRE_BATCH_TRACE"); trace_ = t && t[0] == '1'; }
     Batcher(const Batcher&) = delete;
     Batcher& operator=(const Batcher&) = delete;
 
@@ -147,7 +150,7 @@ class Batcher {
                 be_.start();
                 // staging for the three slots of a steady stream now, at this first shape (pinning 3 x 2 x max_batch images takes tens
                 // of ms): the first job pays it once, instead of later jobs paying it one slot at a time in the middle of a stream
-                for (int i = 0; i < kSlotsEager; ++i) be_.reserve(slots_[i].b, ib * (size_t)be_.max_batch(), be_.max_batch());
+                for (int i = 0; i < kSlotsEager; ++i) be_.reserve(slots_[i].b, std::max(ib, be_.out_bytes(h, w)) * (size_t)be_.max_batch(), be_.max_batch());
                 launcher_ = std::thread([this] { launcher_loop(); });
                 completer_ = std::thread([this] { completer_loop(); });
                 started_ = true;
@@ -187,9 +190,9 @@ class Batcher {
         }
         const int st = j->status;
         if (st == IRE_OK) {
-            const size_t ib = (size_t)j->h * j->w * 3;
+            const size_t ob = be_.out_bytes(j->h, j->w);
             // the ONE host copy of the output: pinned slot -> caller's buffer, in the caller's thread
-            if (out_rgb) std::memcpy(out_rgb, S ? S->b.pin_out + ib * j->idx : j->out.data(), ib);
+            if (out_rgb) std::memcpy(out_rgb, S ? S->b.pin_out + ob * j->idx : j->out.data(), ob);
             if (scores_out) std::memcpy(scores_out, j->scores, sizeof(double) * 7);
             if (t) *t = j->t;
         } else if (err_out) *err_out = j->err;
@@ -246,13 +249,13 @@ class Batcher {
             if (S.h == h && S.w == w && (int)S.jobs.size() < mb) return *it;
         }
         int pick = -1;
-        const size_t need = (size_t)h * w * 3 * (size_t)mb;
+        const size_t need = std::max((size_t)h * w * 3, be_.out_bytes(h, w)) * (size_t)mb;
         for (int i = 0; i < kSlots && pick < 0; ++i) if (slots_[i].state == BatchSlot::FREE && slots_[i].b.cap >= need) pick = i;     // one whose staging exists
         for (int i = 0; i < kSlots && pick < 0; ++i) if (slots_[i].state == BatchSlot::FREE) pick = i;
         for (int i = 0; i < kSlots && pick < 0; ++i) {
             BatchSlot& S = slots_[i];
             if (S.state != BatchSlot::DONE || S.reading) continue;
-            const size_t ib = (size_t)S.h * S.w * 3;
+            const size_t ib = be_.out_bytes(S.h, S.w);
             // job by job, each move complete before the slot forgets the job: a bad_alloc half way leaves a consistent DONE slot
             for (auto& j : S.jobs)
                 if (j->slot == &S) {
@@ -357,6 +360,14 @@ class Batcher {
                 const auto go = std::min(S.last_arrival + std::chrono::microseconds(kLingerQuietUs), S.first_arrival + std::chrono::microseconds(kLingerMaxUs));
                 if (now < go) { (void)wait_deadline(qcv_, lk, go); continue; }     // an arrival re-evaluates; otherwise one wake-up at the deadline
             }
+            if (trace_) {
+                const auto now = clk::now();
+                std::fprintf(stderr, "[batch] slot %d n %d full %d quiet_us %lld age_us %lld since_prev_launch_us %lld open %zu inflight %zu\n", si, (int)S.jobs.size(), (int)full,
+                             (long long)std::chrono::duration_cast<std::chrono::microseconds>(now - S.last_arrival).count(),
+                             (long long)std::chrono::duration_cast<std::chrono::microseconds>(now - S.first_arrival).count(),
+                             (long long)std::chrono::duration_cast<std::chrono::microseconds>(now - last_launch_time_).count(), open_order_.size(), inflight_.size());
+                last_launch_time_ = now;
+            }
             // launch: no more reservations, wait for the copies still running in submitting threads
             S.state = BatchSlot::CLOSED;
             open_order_.pop_front();
@@ -426,6 +437,8 @@ class Batcher {
     std::deque<std::shared_ptr<Job>> overflow_;    // submitted while no slot was free: staged by the launcher later
     int last_launched_ = -1;
     Counters cnt_;
+    bool trace_ = false;                           // IRE_BATCH_TRACE=1: one stderr line per launched batch (why it went, how long it gathered)
+    clk::time_point last_launch_time_ = clk::now();
     std::thread launcher_, completer_;
     bool stop_ = false, launcher_done_ = false, started_ = false;
 };

@@ -139,12 +139,25 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
 #endif
     };
 
+    // workgroup TIMELINE (diagnostic build -DIRE_W4_TL, tools/r04_tl.sh; layout as conv_w4.hip): entry (0), fold done (1), prologue done (2), exit (12)
+    auto tl = [&](int slot) {
+#ifdef IRE_W4_TL
+        if (a.stamps && tid == 0) {
+            a.stamps[(size_t)blockIdx.x * 32 + slot * 2] = __builtin_amdgcn_s_memrealtime();
+            a.stamps[(size_t)blockIdx.x * 32 + slot * 2 + 1] = __builtin_amdgcn_s_memtime();
+        }
+#else
+        (void)slot;
+#endif
+    };
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     PersistCursor cursor(a.tiles_x, a.tiles_y, a.nimg, K::NBLK, NKC);   // item = (tile, 64-cout block); a cursor step is one 32-channel stage
     const int n_items = cursor.my_items;
     if (n_items == 0) return;
     const int n_stages = n_items * NKC;
+    tl(0);
     if (a.gn_stats) gn_fold(a, smem, cursor.first_img, cursor.last_img, 512);
+    tl(1);
 
     {   // weights and bias stay in LDS for the whole kernel
         // resident weights: all of them; streamed: the slab of this workgroup's first stage (slot 0), the producers do the rest
@@ -161,6 +174,7 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
         for (int i = tid; i < nim * C; i += THREADS) cd[i] = ab[i];
     }
     __syncthreads();
+    tl(2);
 
     if (__builtin_amdgcn_readfirstlane(wave) >= 8) {
         // =============================== producers: waves 8..11 ===============================================================
@@ -809,8 +823,10 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
         cs = cursor.next();
         c3_barrier();
         stamp(5);
+        tl(3 + (t < 8 ? t : 8));
     }
     flush_stats();
+    tl(12);
 }
 
 }  // namespace

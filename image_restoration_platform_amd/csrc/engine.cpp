@@ -3,6 +3,7 @@
 // (SURVEY.md Appendix C), which stands behind GeminiClient.restoreImage
 // (server-node/src/clients/geminiClient.js:32-97).
 #include "engine.hpp"
+#include "encode.hpp"
 
 #include <chrono>
 #include <cmath>
@@ -81,7 +82,7 @@ Engine::Engine(const ire_config& cfg) {
     if (max_batch_ > 64) fail(IRE_ERR_INVALID_INPUT, "invalid max_batch (1..64)");
     num_lanes_ = cfg.num_streams > 0 ? cfg.num_streams : 1;
     if (num_lanes_ > 16) num_lanes_ = 16;
-    if (cfg.flags != 0) fail(IRE_ERR_INVALID_INPUT, "invalid ire_config.flags (reserved, must be 0)");
+    if (cfg.flags & ~(uint32_t)IRE_FLAG_RESULT_PNG_BASE64) fail(IRE_ERR_INVALID_INPUT, "invalid ire_config.flags (unknown bits set)");
     flags_ = cfg.flags;
     if (const char* v = std::getenv("IRE_CONV_V1")) rb_tile_h_ = (v[0] == '1') ? 8 : kRbTileH;
     if (const char* v = std::getenv("IRE_ACT_SPLIT_MINC")) act_split_min_c_ = std::atoi(v);
@@ -137,6 +138,16 @@ Engine::Engine(const ire_config& cfg) {
 Engine::~Engine() {
     (void)hipSetDevice(device_);
     (void)hipDeviceSynchronize();
+    if (stamps_dev_ && std::getenv("IRE_STAMPS_RAW")) {     // diagnostic builds with their own stamp layout (conv_pk.hip PK_TICKS): the whole buffer, one value per line
+        std::vector<unsigned long long> h(8 * 2 * 64 * 10);
+        (void)hipMemcpy(h.data(), stamps_dev_, h.size() * 8, hipMemcpyDeviceToHost);
+        if (FILE* f = std::fopen(std::getenv("IRE_STAMPS_RAW"), "w")) {
+            for (size_t i = 0; i < h.size(); ++i) std::fprintf(f, "%llu\n", h[i]);
+            std::fclose(f);
+        }
+        (void)hipFree(stamps_dev_);
+        stamps_dev_ = nullptr;
+    }
     if (stamps_dev_ && !stamps_tl_.empty()) {       // workgroup timeline (conv_w4.hip `tl`): raw stamps, one row per workgroup and slot
         std::vector<unsigned long long> h(8 * 2 * 64 * 10);
         (void)hipMemcpy(h.data(), stamps_dev_, h.size() * 8, hipMemcpyDeviceToHost);
@@ -180,7 +191,7 @@ Engine::~Engine() {
     for (void* p : net_.allocs) (void)hipFree(p);
     for (void* p : table_allocs_) (void)hipFree(p);
     for (void* p : {(void*)d_in_, (void*)d_out_, (void*)d_jpeg_, (void*)d_sums_, (void*)d_scores_, (void*)d_label_,
-                    (void*)d_cond_, (void*)d_film_, (void*)d_fL_, (void*)d_fQ_, (void*)d_fsad_, (void*)d_fmisc_, (void*)d_fwlut_, (void*)d_pp_tab_, (void*)d_pp_mid_, (void*)d_pp_in_, (void*)d_pp_out_})
+                    (void*)d_cond_, (void*)d_film_, (void*)d_fL_, (void*)d_fQ_, (void*)d_fsad_, (void*)d_fmisc_, (void*)d_fwlut_, (void*)d_pp_tab_, (void*)d_pp_mid_, (void*)d_pp_in_, (void*)d_pp_out_, (void*)d_enc_scratch_, (void*)d_enc_io_})
         if (p) (void)hipFree(p);
     for (auto& L : lanes_) {
         if (L.stream) (void)hipStreamDestroy(L.stream);
@@ -624,6 +635,44 @@ void Engine::leave(hipStream_t s) {
     if (hipEventRecord(busy_ev_, s) == hipSuccess) busy_recorded_ = true;
 }
 
+void Engine::encode_png_base64_device(const uint8_t* d_rgb, int n, int h, int w, uint8_t* d_chars, size_t stride, hipStream_t s) {
+    if (!d_rgb || !d_chars || n < 1 || n > max_batch_) fail(IRE_ERR_INVALID_INPUT, "invalid arguments to the PNG encoder (1..max_batch images)");
+    if (h < 1 || w < 8 || w % 8 || h > 16384 || w > 16384) fail(IRE_ERR_INVALID_INPUT, "invalid image size for the PNG encoder: width must be a multiple of 8");
+    if (stride < png_base64_chars(h, w)) fail(IRE_ERR_INVALID_INPUT, "invalid stride for the PNG encoder: smaller than ire_png_base64_bytes(h, w)");
+    const size_t per = (png_scratch_bytes(h, w) + 255) / 256 * 256, need = per * (size_t)n;
+    if (need > enc_scratch_cap_) {
+        IRE_HIP(hipDeviceSynchronize());
+        if (d_enc_scratch_) IRE_HIP(hipFree(d_enc_scratch_));
+        d_enc_scratch_ = nullptr; enc_scratch_cap_ = 0;
+        d_enc_scratch_ = (uint8_t*)dalloc(need);
+        enc_scratch_cap_ = need;
+    }
+    // (the tickets must start at zero; the kernels leave them at zero: one memset per geometry change would do, one per call is 3 us)
+    IRE_HIP(hipMemsetAsync(d_enc_scratch_, 0, need, s));
+    for (int i = 0; i < n; ++i)
+        encode_png_base64_launch(d_rgb + (size_t)i * h * w * 3, h, w, d_enc_scratch_ + per * i, d_chars + stride * i, s);
+}
+
+void Engine::encode_png_base64_host(const uint8_t* rgb, int n, int h, int w, uint8_t* chars, size_t stride) {
+    if (!rgb || !chars) fail(IRE_ERR_INVALID_INPUT, "invalid arguments to the PNG encoder: null buffer");
+    if (n < 1 || n > max_batch_ || h < 1 || w < 8 || w % 8 || h > 16384 || w > 16384) fail(IRE_ERR_INVALID_INPUT, "invalid arguments to the PNG encoder (1..max_batch images, width a multiple of 8)");
+    const size_t ib = (size_t)h * w * 3, cb = png_base64_chars(h, w), cpad = (cb + 255) / 256 * 256;
+    const size_t need = (ib + cpad) * (size_t)n;
+    if (need > enc_io_cap_) {
+        IRE_HIP(hipDeviceSynchronize());
+        if (d_enc_io_) IRE_HIP(hipFree(d_enc_io_));
+        d_enc_io_ = nullptr; enc_io_cap_ = 0;
+        d_enc_io_ = (uint8_t*)dalloc(need);
+        enc_io_cap_ = need;
+    }
+    hipStream_t s = main_stream_;
+    IRE_HIP(hipMemcpyAsync(d_enc_io_, rgb, ib * n, hipMemcpyHostToDevice, s));
+    uint8_t* d_txt = d_enc_io_ + ib * n;
+    encode_png_base64_device(d_enc_io_, n, h, w, d_txt, cpad, s);
+    for (int i = 0; i < n; ++i) IRE_HIP(hipMemcpyAsync(chars + stride * i, d_txt + cpad * i, cb, hipMemcpyDeviceToHost, s));
+    IRE_HIP(hipStreamSynchronize(s));
+}
+
 void Engine::free_workspace() {
     for (void* p : ws_allocs_) (void)hipFree(p);
     ws_allocs_.clear();
@@ -926,7 +975,7 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     a.stamps = nullptr;
     a.prio_young = prio_young_;
     a.w4_waves = (a.ab == nullptr) ? w4_waves_ : 8;
-    if (stamps_dev_ && rb && cw.cout == stamps_cout_ && (cw.kind == CONV_RB2) == stamps_resid_ && (!stamps_taken_ || !stamps_tl_.empty())) {
+    if (stamps_dev_ && rb && cw.cout == stamps_cout_ && (cw.kind == CONV_RB2) == stamps_resid_ && (!stamps_taken_ || !stamps_tl_.empty() || std::getenv("IRE_STAMPS_RAW"))) {
         a.stamps = stamps_dev_;
         stamps_taken_ = true;
     }
@@ -982,7 +1031,10 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
         }
         // the producer / consumer form (conv_pk.hip) takes the 128-cout bf16 launches with a fused activation whose workgroups stay
         // within its coefficient table; same slabs, bit-identical results
-        if (use_pk_ && !a.fp8 && a.ab != nullptr && a.w4_nt != 64 && cw.cin == cw.cout && conv_pk_fits(cw.cout, a.tiles_x * a.tiles_y, g.nimg)) {
+        // (use_pk_ 1: the convs without a residual; 2: all of them -- the residual variant's epilogue fetches its 128 KB of residual rows per item
+        //  in one burst with too few registers to wait in: 208 vs conv_w4's 181 us at C = 128, profiles/r04_experiments.md)
+        if (use_pk_ && (use_pk_ >= 2 || cw.kind != CONV_RB2) && !a.fp8 && a.ab != nullptr && a.w4_nt != 64 && cw.cin == cw.cout &&
+            conv_pk_fits(cw.cout, a.tiles_x * a.tiles_y, g.nimg)) {
             conv_pk_launch(cw.kind == CONV_RB2, a, R.stream); kname = "conv_pk";
         } else {
             conv_w4_launch(cw.kind == CONV_RB2, a, R.stream); kname = "conv_w4";

@@ -159,6 +159,10 @@ public:
     void preprocess_device(const uint8_t* d_rgb, int h, int w, int orientation, int max_dim, uint8_t* d_out, int out_h, int out_w,
                            hipStream_t s);
     void preprocess_host(const uint8_t* rgb, int h, int w, int orientation, int max_dim, uint8_t* out, int out_h, int out_w);
+    // encode.hip: n images [h][w][3] -> n x png_base64_chars(h, w) characters, `stride` bytes apart (device buffers, asynchronous on s)
+    void encode_png_base64_device(const uint8_t* d_rgb, int n, int h, int w, uint8_t* d_chars, size_t stride, hipStream_t s);
+    void encode_png_base64_host(const uint8_t* rgb, int n, int h, int w, uint8_t* chars, size_t stride);
+    uint32_t flags() const { return flags_; }
 
     void debug_sums(int n, uint64_t* out);
     void debug_capture(bool on) { capture_ = on; captured_.clear(); }
@@ -220,7 +224,7 @@ private:
     int w4_fused_min_c_ = 128;      // IRE_W4_FUSED_MINC: ResBlock convs with fused activation and cout >= this run on conv_w4's fused variant
     int w4_waves_ = 8;            // IRE_W4_WAVES=4: the one-wave-per-SIMD form, pre-activated inputs only (fused activation needs the 8-wave form)
     int w4_split_ = 1;            // IRE_W4_SPLIT=0: never use the 64-cout items
-    int use_pk_ = 1;              // C >= 128 ResBlock convs (128-cout items, fused activation) on conv_pk.hip's producer / consumer workgroups (IRE_PK=0: conv_w4.hip)
+    int use_pk_ = 1;              // C >= 128 ResBlock convs (128-cout items, fused activation) on conv_pk.hip's producer / consumer workgroups: 1 = the convs without a residual, 2 = all (IRE_PK=0: conv_w4.hip)
     int use_w4_ = 1;              // C >= 128 ResBlock convs on conv_w4.hip (IRE_W4=0: conv_rb.hip; IRE_W4_WAVES=4|8)
     int fp8_mx_ = 1;              // fp8: the block-scaled K = 64 MFMA (conv_f8.hip); IRE_FP8_MX=0: the same-rate 32x32x16 fp8 form in conv_w4.hip
     int down_rb_ = 1;             // stride-2 `down` convs on conv_down.hip's pipelined phase kernel (IRE_DOWN_RB=0: the v1 kernel)
@@ -274,6 +278,9 @@ private:
     uint8_t* d_pp_mid_ = nullptr;
     uint8_t* d_pp_in_ = nullptr;
     uint8_t* d_pp_out_ = nullptr;
+    uint8_t* d_enc_scratch_ = nullptr;    // encode.hip: per image: the PNG file + checksum state
+    uint8_t* d_enc_io_ = nullptr;         // host entry: pixels in | characters out
+    size_t enc_scratch_cap_ = 0, enc_io_cap_ = 0;
 
     // network
     Net net_;

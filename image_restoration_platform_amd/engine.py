@@ -44,6 +44,7 @@ class Engine:
         cfg.num_streams = num_streams
         cfg.weights_path = weights_path.encode() if weights_path else None
         cfg.flags = flags
+        self._flags = flags
         h = ctypes.c_void_p()
         self._h = None
         self._check(self._lib.ire_init(ctypes.byref(cfg), ctypes.byref(h)))
@@ -174,12 +175,45 @@ class Engine:
         return int(self._lib.ire_max_batch_for(self._h, int(h), int(w)))
 
     def poll(self, job, timeout_ms=-1):
+        """-> (restored [H,W,3] uint8 -- or, for an engine created with flags=IRE_FLAG_RESULT_PNG_BASE64, the `bytes` of the base64 text
+        of its PNG file --, scores[7], timings)"""
         handle, h, w = job
-        out = np.empty((h, w, 3), np.uint8)
+        text = bool(getattr(self, "_flags", 0) & _lib.IRE_FLAG_RESULT_PNG_BASE64)
+        out = np.empty(self.png_base64_bytes(h, w), np.uint8) if text else np.empty((h, w, 3), np.uint8)
         scores = np.zeros(7, np.float64)
         t = _lib.IreTimings()
         self._check(self._lib.ire_poll(self._h, handle, timeout_ms, _ptr(out), _ptr(scores), ctypes.byref(t)))
+        if text:
+            out = out.tobytes()
         return out, scores, {"classify_ms": t.classify_ms, "restore_ms": t.restore_ms, "total_ms": t.total_ms}
+
+    def png_base64_bytes(self, h, w):
+        return int(self._lib.ire_png_base64_bytes(int(h), int(w)))
+
+    def encode_png_base64(self, rgb):
+        """[N,H,W,3] (or [H,W,3]) uint8 -> list of N `bytes` (one for a single image): the base64 text of a PNG file of each image,
+        encoded on the device (stored deflate blocks: every PNG decoder reads it)."""
+        single = np.asarray(rgb).ndim == 3
+        x = self._as_batch(rgb)
+        n, h, w, _ = x.shape
+        cb = self.png_base64_bytes(h, w)
+        if cb == 0:
+            raise EngineError(_lib.IRE_ERR_INVALID_INPUT, "invalid image size for the PNG encoder: width must be a multiple of 8")
+        stride = (cb + 15) // 16 * 16
+        out = np.empty((n, stride), np.uint8)
+        self._check(self._lib.ire_encode_png_base64(self._h, _ptr(x), n, h, w, _ptr(out), stride))
+        res = [out[i, :cb].tobytes() for i in range(n)]
+        return res[0] if single else res
+
+    def encode_png_base64_tensor(self, rgb_u8, stream=None):
+        """cuda uint8 [N,H,W,3] -> cuda uint8 [N, chars] ASCII (asynchronous on the stream)."""
+        import torch
+        n, h, w, _ = rgb_u8.shape
+        cb = self.png_base64_bytes(h, w)
+        out = torch.empty((n, cb), dtype=torch.uint8, device=rgb_u8.device)
+        self._check(self._lib.ire_encode_png_base64_device(self._h, ctypes.c_void_p(rgb_u8.data_ptr()), n, h, w, ctypes.c_void_p(out.data_ptr()), cb,
+                                                           self._stream_ptr(stream)))
+        return out
 
     def release(self, job):
         """Give a submitted job up without fetching it (after a poll() timeout the caller will not repeat): ire_job_release."""

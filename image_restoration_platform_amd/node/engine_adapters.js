@@ -29,10 +29,14 @@ function createEngine(opts) {
   const addon = opts.addon || loadAddon();
   const lib = opts.libPath || path.join(__dirname, '..', 'lib', 'libire.so');
   // throws Error('service unavailable: ...') when there is no gfx950 device: there is no CPU fallback
-  const handle = addon.init(lib, opts.weightsPath || '', opts.deviceIndex || 0, opts.maxBatch || 8, opts.numStreams || 0);
+  // resultCodec 'png-device': the engine's batcher returns every result as the base64 TEXT of a PNG file encoded on the GPU
+  // (IRE_FLAG_RESULT_PNG_BASE64; csrc/encode.hip) -- the string restorator.js:108 puts on the wire, with no sharp encode and no
+  // Buffer.toString('base64') (1.03 ms of the one JS thread per 1024^2 result) left for this process
+  const textResults = opts.resultCodec === 'png-device';
+  const handle = addon.init(lib, opts.weightsPath || '', opts.deviceIndex || 0, opts.maxBatch || 8, opts.numStreams || 0, textResults ? 1 : 0);
   // seen: Buffer -> {decoded, scores}: RestoratorService hands the SAME Buffer object first to classifier.analyze and then to
   // geminiClient.restoreImage (restorator.js:59-94); remembering it here means one decode and one classification per job
-  return { addon, handle, seen: new WeakMap() };
+  return { addon, handle, seen: new WeakMap(), textResults };
 }
 
 function defaultCodec() {
@@ -117,9 +121,20 @@ function createEngineRestorer(opts) {
         }
         // scores known: not classified again; null: classifies inside.  timeoutMs bounds the wait for the engine's batch: a wedged
         // engine rejects with code ENGINE_TIMEOUT ("timeout: ..." -> TIMEOUT in _classifyError) instead of hanging the promise
-        return engine.addon.restoreAsync(engine.handle, p.data, 1, p.height, p.width, flags, scores || null, timeoutMs);
+        const outBytes = engine.textResults ? engine.addon.pngBase64Bytes(p.height, p.width) : 0;
+        return engine.addon.restoreAsync(engine.handle, p.data, 1, p.height, p.width, flags, scores || null, timeoutMs, outBytes);
       });
-      const restored = (await Promise.all(pending)).map((r) => r.pixels);
+      let restored = (await Promise.all(pending)).map((r) => r.pixels);
+      if (engine.textResults) {
+        jobCounter += 1;
+        if (restored.length === 1 && W === w && H === h) {
+          // nothing was padded, nothing to fuse: the device's text IS the result (a one-byte-per-character string: no transcoding)
+          return { base64Image: restored[0].latin1Slice(0, restored[0].length),
+                   metadata: { providerRequestId: 'ire-' + process.pid + '-' + jobCounter, billedTokens: null, estimatedCostUsd: 0 } };
+        }
+        // padded or multi-view jobs need pixels again: the stored-block PNG inflates at memcpy speed
+        restored = await Promise.all(restored.map(async (t) => (await codec.decode(Buffer.from(t.latin1Slice(0, t.length), 'base64'))).data));
+      }
       let pixels = restored[0];
       if (restored.length > 1) {
         if (H < 64 || W < 64) throw new Error('invalid images: fusion needs at least 64x64 pixels');

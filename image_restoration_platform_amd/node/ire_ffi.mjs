@@ -29,6 +29,9 @@ export function bindIre(libPath) {
     ire_preprocess_plan: ['int', ['int', 'int', 'int', 'int', IP, IP, IP]],
     ire_preprocess: ['int', [P, P, 'int', 'int', 'int', 'int', P, 'int', 'int']],
     ire_preprocess_device: ['int', [P, P, 'int', 'int', 'int', 'int', P, 'int', 'int', P]],
+    ire_png_base64_bytes: ['size_t', ['int', 'int']],
+    ire_encode_png_base64_device: ['int', [P, P, 'int', 'int', 'int', P, 'size_t', P]],
+    ire_encode_png_base64: ['int', [P, P, 'int', 'int', 'int', P, 'size_t']],
     ire_submit: ['int', [P, P, 'int', 'int', 'int', P, PP]],
     ire_poll: ['int', [P, P, 'int', P, P, P]],
     ire_job_release: ['int', [P, P]],

@@ -50,6 +50,7 @@ struct Api {
     decltype(&ire_poll) poll = nullptr;
     decltype(&ire_job_release) job_release = nullptr;
     decltype(&ire_engine_affinity) engine_affinity = nullptr;
+    decltype(&ire_png_base64_bytes) png_base64_bytes = nullptr;
     decltype(&ire_preprocess_plan) preprocess_plan = nullptr;
     decltype(&ire_preprocess) preprocess = nullptr;
     decltype(&ire_get_stats) get_stats = nullptr;
@@ -65,7 +66,7 @@ bool load_api(const char* path, std::string* err) {
     if (g.abi_version() != IRE_ABI_VERSION) { *err = "service unavailable: libire.so ABI version mismatch"; return false; }     // before the symbols a stale library lacks
     SYM(init, "ire_init") SYM(shutdown, "ire_shutdown") SYM(last_error, "ire_last_error") SYM(classify, "ire_classify")
     SYM(restore, "ire_restore") SYM(fuse, "ire_fuse")
-    SYM(submit, "ire_submit") SYM(poll, "ire_poll") SYM(job_release, "ire_job_release") SYM(engine_affinity, "ire_engine_affinity") SYM(preprocess_plan, "ire_preprocess_plan") SYM(preprocess, "ire_preprocess")
+    SYM(submit, "ire_submit") SYM(poll, "ire_poll") SYM(job_release, "ire_job_release") SYM(engine_affinity, "ire_engine_affinity") SYM(png_base64_bytes, "ire_png_base64_bytes") SYM(preprocess_plan, "ire_preprocess_plan") SYM(preprocess, "ire_preprocess")
     SYM(get_stats, "ire_get_stats") SYM(max_batch_for, "ire_max_batch_for")
 #undef SYM
     return true;
@@ -244,7 +245,7 @@ bool waiters_start(napi_env env, ire_engine* eng) {
 
 // submit(kind, engineHandle(external), pixels Buffer, n, h, w, jpegFlags Buffer|null, noise) -> Promise
 napi_value submit(napi_env env, napi_callback_info info, Job::Kind kind) {
-    size_t argc = 8; napi_value argv[8];
+    size_t argc = 9; napi_value argv[9];
     napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
     if (argc < 5) { throw_err(env, "invalid arguments"); return nullptr; }
     void* eng = nullptr;
@@ -309,8 +310,11 @@ napi_value submit(napi_env env, napi_callback_info info, Job::Kind kind) {
             delete j;
             return promise;
         }
+        // (an engine created with IRE_FLAG_RESULT_PNG_BASE64 delivers text: the caller passes its size, pngBase64Bytes(h, w))
+        size_t need_out = need;
+        if (argc > 8) { const int64_t ob = get_i64(env, argv[8]); if (ob > 0) need_out = (size_t)ob; }
         napi_value outbuf; void* op = nullptr;
-        napi_create_buffer(env, need, &op, &outbuf);               // the result: ire_poll writes into it from a waiter thread
+        napi_create_buffer(env, need_out, &op, &outbuf);           // the result: ire_poll writes into it from a waiter thread
         j->out_ptr = (uint8_t*)op;
         napi_create_reference(env, outbuf, 1, &j->out_ref);
         napi_create_reference(env, argv[0], 1, &j->eng_ref);     // the engine outlives its pending jobs
@@ -419,9 +423,19 @@ napi_value max_batch_for_sync(napi_env env, napi_callback_info info) {
 
 void finalize_engine(napi_env, void* data, void*) { if (data && g.shutdown) g.shutdown((ire_engine*)data); }
 
-// init(libPath, weightsPath|null, deviceIndex, maxBatch, numStreams) -> engine handle (throws with the engine's message)
+// pngBase64Bytes(h, w) -> characters of the device-encoded result of an h x w image (0: unsupported size)
+napi_value png_base64_bytes_sync(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value argv[2];
+    napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+    if (argc < 2 || !g.png_base64_bytes) { throw_err(env, "invalid arguments (or engine library not loaded: call init first)"); return nullptr; }
+    napi_value v;
+    napi_create_int64(env, (int64_t)g.png_base64_bytes((int)get_i64(env, argv[0]), (int)get_i64(env, argv[1])), &v);
+    return v;
+}
+
+// init(libPath, weightsPath|null, deviceIndex, maxBatch, numStreams, flags) -> engine handle (throws with the engine's message)
 napi_value init_engine(napi_env env, napi_callback_info info) {
-    size_t argc = 5; napi_value argv[5];
+    size_t argc = 6; napi_value argv[6];
     napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
     char lib[1024] = {0}, wts[1024] = {0}; size_t l = 0;
     if (argc < 1 || napi_get_value_string_utf8(env, argv[0], lib, sizeof(lib), &l) != napi_ok) { throw_err(env, "invalid arguments"); return nullptr; }
@@ -434,6 +448,7 @@ napi_value init_engine(napi_env env, napi_callback_info info) {
     cfg.max_batch = argc > 3 ? (int)get_i64(env, argv[3]) : 8;
     cfg.num_streams = argc > 4 ? (int)get_i64(env, argv[4]) : 0;
     cfg.weights_path = have_w ? wts : nullptr;
+    cfg.flags = argc > 5 ? (uint32_t)get_i64(env, argv[5]) : 0;          // IRE_FLAG_RESULT_PNG_BASE64 = 1
     ire_engine* e = nullptr;
     const int rc = g.init(&cfg, &e);
     if (rc != 0) { throw_err(env, g.last_error()); return nullptr; }
@@ -452,6 +467,7 @@ napi_value module_init(napi_env env, napi_value exports) {
         {"preprocessAsync", nullptr, preprocess_async, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"stats", nullptr, stats_sync, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"maxBatchFor", nullptr, max_batch_for_sync, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"pngBase64Bytes", nullptr, png_base64_bytes_sync, nullptr, nullptr, nullptr, napi_default, nullptr},
     };
     napi_define_properties(env, exports, sizeof(d) / sizeof(d[0]), d);
     return exports;

@@ -97,6 +97,20 @@ async function restoreLikeReference(classifier, restorer, imageBuffer) {
     out.once = { scoresEqual: JSON.stringify(an) === JSON.stringify(out.scores), pixelsEqual: rr.base64Image === r.restoredImage, cached: engine.seen.has(b2),
                  batches: hl.metrics().batches - s0.batches };
   }
+  if (spec.cfg0) {
+    // BASELINE cfg 0 through the Node seam: one 256 x 256 job, default prompt, no fusion
+    const r0 = await restoreLikeReference(classifier, restorer, fs.readFileSync(spec.cfg0));
+    out.cfg0 = { success: r0.success, sha: r0.success ? require('crypto').createHash('sha256').update(Buffer.from(r0.restoredImage, 'base64').slice(9)).digest('hex') : null,
+                 scores: r0.degradationAnalysis };
+  }
+  if (spec.textResults) {
+    // resultCodec 'png-device': the engine's batcher hands back the base64 text of a device-encoded PNG; restoreImage passes it on as it is
+    const engine2 = ad.createEngine({ weightsPath: spec.weights, maxBatch: 8, resultCodec: 'png-device' });
+    const restorer2 = ad.createEngineRestorer({ engine: engine2, codec: rawCodec });
+    const tr = await restorer2.restoreImage({ prompt: 'p', images: [fs.readFileSync(spec.image8)] });
+    out.textResult = { chars: tr.base64Image.length, sha: require('crypto').createHash('sha256').update(tr.base64Image, 'latin1').digest('hex'),
+                       head: Buffer.from(tr.base64Image.slice(0, 16), 'base64').toString('latin1').slice(1, 4) };
+  }
   if (spec.fuse) {
     const views = spec.fuse.map((f) => fs.readFileSync(f));
     const fr = await restorer.restoreImage({ prompt: 'p', images: views });

@@ -55,6 +55,22 @@ def encode_png_base64(rgb):
     return base64.b64encode(bio.getvalue()).decode("ascii")
 
 
+def encode_jpeg_base64(rgb, quality=85):
+    """JPEG q85 4:4:4, the reference's own output settings where it encodes (imagePreprocess.js:57-64)."""
+    from PIL import Image
+    bio = io.BytesIO()
+    Image.fromarray(rgb, "RGB").save(bio, format="JPEG", quality=quality, subsampling=0)
+    return base64.b64encode(bio.getvalue()).decode("ascii")
+
+
+# How the restored image becomes the base64 string of restorator.js:108 (IRE_RESULT_CODEC):
+#   png         host PIL PNG (zlib level 6): ~0.2 s of one core per 1024^2 photograph -- the default, what round 3 shipped
+#   jpeg        host PIL JPEG q85 4:4:4 (the reference's own settings where it encodes: imagePreprocess.js:57-64): ~15 ms
+#   png-device  a PNG of stored deflate blocks + its base64 text written by the GPU (csrc/encode.hip): no host codec work at all;
+#               with an engine created with IRE_FLAG_RESULT_PNG_BASE64 the batcher hands the text back instead of pixels
+RESULT_CODEC = os.environ.get("IRE_RESULT_CODEC", "png")
+
+
 def pad_to_multiple(rgb, m=8, min_size=16):
     """edge-replicate pad so H, W are multiples of m (RestoreNet has three stride-2 levels)."""
     h, w, _ = rgb.shape
@@ -111,9 +127,17 @@ class EngineClassifier:
 class EngineRestorer:
     """geminiClient seam: restore_image(prompt, images, user_context) -> {base64Image, metadata}."""
 
-    def __init__(self, engine, logger=None):
+    def __init__(self, engine, logger=None, result_codec=None):
         self.engine = engine
         self.logger = logger
+        self.result_codec = result_codec or RESULT_CODEC
+
+    def _encode(self, result):
+        if self.result_codec == "jpeg":
+            return encode_jpeg_base64(result)
+        if self.result_codec == "png-device" and result.shape[1] % 8 == 0:
+            return self.engine.encode_png_base64(result).decode("ascii")
+        return encode_png_base64(result)          # (png-device on a width that is not a multiple of 8: the host encoder)
 
     def restore_image(self, prompt, images, user_context=None):
         if not images or len(images) > 3:
@@ -135,9 +159,16 @@ class EngineRestorer:
                 # condition on the image's own scores (what analyze() reports), never on its replicate-padded copy's
                 scores = self.engine.classify(rgb, is_jpeg=(fmt == "jpeg"))[0][0]
             jobs.append((self.engine.submit(padded, is_jpeg=(fmt == "jpeg"), scores=scores), h, w))
+        text_engine = bool(getattr(self.engine, "_flags", 0) & 1)          # IRE_FLAG_RESULT_PNG_BASE64: ire_poll returns the text
+        if text_engine and len(jobs) == 1 and decoded[0][0].shape[0] % 8 == 0 and decoded[0][0].shape[1] % 8 == 0 and decoded[0][0].shape[0] >= 16:
+            text, _, _ = self.engine.poll(jobs[0][0])                     # no padding was cut off: the device's text IS the result
+            return {"base64Image": text.decode("ascii"),
+                    "metadata": {"providerRequestId": f"ire-{uuid.uuid4()}", "billedTokens": None, "estimatedCostUsd": 0}}
         restored = []
         for job, h, w in jobs:
             out, _, _ = self.engine.poll(job)
+            if text_engine:                                               # a flagged engine and an image that needs cropping: decode the stored PNG (a memcpy-speed inflate)
+                out = decode_image(base64.b64decode(out))[0]
             restored.append(np.ascontiguousarray(out[:h, :w]))
         if len(restored) == 1:
             result = restored[0]
@@ -147,7 +178,7 @@ class EngineRestorer:
             fused, _ = self.engine.fuse(padded, noise_score=-1.0)
             result = np.ascontiguousarray(fused[:views.shape[1], :views.shape[2]])
         return {
-            "base64Image": encode_png_base64(result),
+            "base64Image": self._encode(result),
             "metadata": {"providerRequestId": f"ire-{uuid.uuid4()}", "billedTokens": None, "estimatedCostUsd": 0},
         }
 

@@ -41,7 +41,9 @@ def get_service():
     with _lock:
         if _state["service"] is None:
             try:
-                eng = Engine(device_index=0, max_batch=8)
+                from ..restorator import RESULT_CODEC
+                # IRE_RESULT_CODEC=png-device: the batcher returns the base64 text of a device-encoded PNG (csrc/encode.hip)
+                eng = Engine(device_index=0, max_batch=8, flags=1 if RESULT_CODEC == "png-device" else 0)
             except Exception as e:  # noqa: BLE001 -- EngineError or a missing library
                 _state["error"] = str(e)
                 raise

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define IRE_ABI_VERSION 3   /* 3: ire_job_release, ire_affinity_plan, ire_engine_affinity, ire_profile_report; ire_profile_enable mode bits 8..; ire_config.flags checked */
+#define IRE_ABI_VERSION 3   /* 3: ire_job_release, ire_affinity_plan, ire_engine_affinity, ire_profile_report, ire_encode_png_base64*, IRE_FLAG_RESULT_PNG_BASE64; ire_profile_enable mode bits 8..; ire_config.flags checked */
 
 typedef enum ire_status {
     IRE_OK = 0,
@@ -72,8 +72,13 @@ typedef struct ire_config {
                                  (default 0 = engine's choice)                           */
     const char* weights_path; /* RestoreNet-v0 weight file (DESIGN.md "weight file");
                                  NULL: classify/fuse only until ire_load_weights         */
-    uint32_t flags;           /* reserved, must be 0                                     */
+    uint32_t flags;           /* IRE_FLAG_* bits; unknown bits are rejected               */
 } ire_config;
+/* The batcher (ire_submit / ire_poll) delivers every result as the base64 TEXT of a PNG file of the restored image, encoded
+ * on the device (ire_encode_png_base64_device below), instead of raw pixels: ire_poll's out_rgb then receives
+ * ire_png_base64_bytes(h, w) ASCII characters -- the string restorator.js:108 puts on the wire, with no codec or base64 work
+ * left for the host. */
+#define IRE_FLAG_RESULT_PNG_BASE64 1u
 
 
 
@@ -142,13 +147,25 @@ int ire_preprocess(ire_engine* e, const uint8_t* rgb, int h, int w, int orientat
 int ire_preprocess_device(ire_engine* e, const uint8_t* d_rgb, int h, int w, int orientation, int max_dim,
                           uint8_t* d_out_rgb, int out_h, int out_w, void* stream);
 
+/* ---- result side of the seam: restored pixels -> base64 text of a PNG file, on the device (restorator.js:108: `restoredImage` is
+ * a base64 string of an ENCODED image; geminiClient.js:75-88) ----
+ * The file: signature, IHDR (8-bit RGB), ONE IDAT chunk = a zlib stream of STORED deflate blocks (scanline filter 0) with its
+ * Adler-32, its CRC-32, IEND -- every PNG decoder reads it; 0.2 % larger than the pixels.  The text: RFC 4648 base64, '=' padded,
+ * no terminator.  Bit-exact against zlib / base64 / a PNG decoder (oracle/encode.py).  w a multiple of 8; n <= max_batch.
+ * ire_png_base64_bytes: characters per image (0: unsupported size).  Images / texts are h*w*3 / stride_bytes apart. */
+size_t ire_png_base64_bytes(int h, int w);
+int ire_encode_png_base64_device(ire_engine* e, const uint8_t* d_rgb, int n, int h, int w, uint8_t* d_chars, size_t stride_bytes,
+                                 void* stream);
+int ire_encode_png_base64(ire_engine* e, const uint8_t* rgb, int n, int h, int w, uint8_t* chars, size_t stride_bytes);
+
 /* ---- async batcher (restoreBatch's in-flight promises) ---------------------------------- */
 typedef struct ire_job ire_job;
 /* Queue one h x w image for restoration; jobs of equal shape are coalesced into batches of up
  * to max_batch.  The input is copied before return.  scores: the 7 doubles a previous ire_classify
  * of this image returned (the job is then not classified again), or NULL => classify inside. */
 int ire_submit(ire_engine* e, const uint8_t* rgb, int h, int w, int is_jpeg, const double* scores, ire_job** job_out);
-/* Wait up to timeout_ms (<0: forever) for the job; on IRE_OK out_rgb (h*w*3), scores_out (7, may
+/* Wait up to timeout_ms (<0: forever) for the job; on IRE_OK out_rgb (h*w*3 pixel bytes, or with IRE_FLAG_RESULT_PNG_BASE64
+ * ire_png_base64_bytes(h, w) characters), scores_out (7, may
  * be NULL) and t (may be NULL) are filled and the job is released; any other status but
  * IRE_ERR_TIMEOUT releases it too.  IRE_ERR_TIMEOUT leaves the job pending and the handle valid:
  * poll again, or give the job up with ire_job_release.  One thread at a time per handle. */

@@ -54,6 +54,7 @@ struct StubBackend {
     }
     ~StubBackend() { { std::lock_guard<std::mutex> lk(qmu); stop = true; } qcv.notify_all(); dev.join(); }
     int max_batch() const { return mb; }
+    size_t out_bytes(int h, int w) const { return (size_t)h * w * 3; }
     void start() {}
     void thread_enter(const char*) {}
     void reserve(SlotBufs& b, size_t bytes, int max_batch) {

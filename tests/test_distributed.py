@@ -87,6 +87,41 @@ def test_bench_starts_its_own_ranks_and_reports_n_gpus(tmp_path):
     assert r1.returncode == 0 and json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
 
 
+def test_bench_ranks_report_disjoint_cpu_plans(tmp_path):
+    """8-rank host feeding (restorator.js:198-211): every rank's service threads stay on ITS GPU's NUMA node,
+    on that GPU's share of the node.  `bench.py --gpus 4 --stub` over a fabricated two-socket sysfs: each rank asks libire.so for
+    the plan of its own PCI address (ire_affinity_plan), rank 0 reports all of them the way host_path_ranks does on a real node:
+    the plans are pairwise disjoint, each inside its GPU's node, SMT siblings together."""
+    import json
+    import subprocess
+    from test_batcher_native import _fake_sysfs
+    gpus0, gpus1 = ["0000:05:00.0", "0000:15:00.0"], ["0000:85:00.0", "0000:95:00.0"]
+    _fake_sysfs(tmp_path, {0: ("0-15,32-47", gpus0), 1: ("16-31,48-63", gpus1)})
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(IRE_STUB_SYSFS=str(tmp_path), IRE_STUB_BDFS=",".join([gpus0[0], gpus1[0], gpus0[1], gpus1[1]]))     # ranks alternate sockets
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "0", "--stub"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    rows = j["host_path"]["per_rank"]
+    assert [x["rank"] for x in rows] == [0, 1, 2, 3] and [x["numa_node"] for x in rows] == [0, 1, 0, 1]
+
+    def cpus(l):
+        out = set()
+        for part in l.split(","):
+            a, _, b = part.partition("-")
+            out.update(range(int(a), int(b or a) + 1))
+        return out
+    sets = [cpus(x["cpulist"]) for x in rows]
+    node = [set(range(0, 16)) | set(range(32, 48)), set(range(16, 32)) | set(range(48, 64))]
+    for i, s in enumerate(sets):
+        assert len(s) == 16 and s <= node[rows[i]["numa_node"]]
+        assert all((c + 32) in s for c in s if c < 32)                 # a core and its SMT sibling go to the same rank
+        for t in sets[:i]:
+            assert not (s & t)
+    assert set().union(*sets) == set(range(64))
+
+
 def _fusion_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)

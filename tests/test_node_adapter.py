@@ -55,7 +55,11 @@ def test_node_seams_match_python_host(engine, tmp_path):
         vf.append(str(p))
     f8 = tmp_path / "a8.raw"
     f8.write_bytes(_raw(synth.image(2, 72, 104)))
-    out = _run(tmp_path, {"weights": weights.ensure_default(0), "image": str(f), "image8": str(f8), "fuse": vf, "worker": True, "concurrent": 8})
+    f0 = tmp_path / "cfg0.raw"
+    img0 = synth.image(3, 256, 256)
+    f0.write_bytes(_raw(img0))
+    out = _run(tmp_path, {"weights": weights.ensure_default(0), "image": str(f), "image8": str(f8), "fuse": vf, "worker": True, "concurrent": 8,
+                          "cfg0": str(f0), "textResults": True})
     assert out["engine"] is True and out["allEqual"] is True and out["success"] is True
     scores, _ = engine.classify(img, is_jpeg=True)
     from image_restoration_platform_amd.prompt_enhancer import KEYS
@@ -72,6 +76,17 @@ def test_node_seams_match_python_host(engine, tmp_path):
     assert cc["images"] == 8 and cc["batches"] <= 2 and cc["allEqual"] and cc["sameAsSingle"], cc
     assert cc["health"]["ok"] is True and cc["health"]["info"]["status"] == "ok" and cc["health"]["info"]["imagesPerSec"] > 0
     assert out["once"] == {"scoresEqual": True, "pixelsEqual": True, "cached": True, "batches": 1}
+    # BASELINE cfg 0 (one 256 x 256 job, default prompt, no fusion) through the Node seam == the Python host
+    sc0, _ = engine.classify(img0, is_jpeg=True)
+    assert out["cfg0"]["success"] is True and [out["cfg0"]["scores"][k] for k in KEYS] == [float(x) for x in sc0[0]]
+    assert out["cfg0"]["sha"] == hashlib.sha256(np.ascontiguousarray(engine.restore(img0, scores=sc0, is_jpeg=True)[0]).tobytes()).hexdigest()
+    # resultCodec 'png-device': restoreImage's base64Image is the device's text -- the oracle's PNG (stored deflate) of the same restored pixels
+    from oracle import encode as oenc
+    img8 = synth.image(2, 72, 104)
+    sc8, _ = engine.classify(img8, is_jpeg=True)
+    want = oenc.png_base64(engine.restore(img8, scores=sc8, is_jpeg=True)[0])
+    assert out["textResult"]["head"] == "PNG" and out["textResult"]["chars"] == len(want)
+    assert out["textResult"]["sha"] == hashlib.sha256(want).hexdigest()
     wk = out["worker"]                                   # the BullMQ-style worker over the engine-backed seams
     assert wk["good"]["status"] == "succeeded" and wk["good"]["providerRequestId"].startswith("ire-")
     assert wk["err"]["unrecoverable"] is True and wk["err"]["type"] == "INVALID_INPUT"

@@ -93,7 +93,7 @@ def test_seeded_random_shapes_vs_fp32_oracle(engine, weights0):
 
 @pytest.mark.parametrize("env", [{"IRE_W4": "0"}, {"IRE_W4_WAVES": "4", "IRE_ACT_SPLIT_MINC": "128"}, {"IRE_W4_WAVES": "4"}, {"IRE_CONV_V1": "1"}, {"IRE_UP_RB_MINC": "64"},
                                  {"IRE_ACT_SPLIT_MINC": "64"}, {"IRE_ACT_SPLIT_MINC": "128"}, {"IRE_UP_SUBPIX": "0"}, {"IRE_UP_FUSE": "0"}, {"IRE_GN_FOLD": "0"}, {"IRE_PC": "0"}, {"IRE_PC": "1"}, {"IRE_PC": "7"}, {"IRE_PC": "3"}, {"IRE_PC": "0", "IRE_GN_FOLD": "0"}, {"IRE_DOWN_RB": "0", "IRE_HEAD_RB": "0"}, {"IRE_STEM_RB": "0"},
-                                 {"IRE_W4_FUSED_MINC": "100000", "IRE_ACT_SPLIT_MINC": "256"}, {"IRE_W4_FUSED_MINC": "100000"}, {"IRE_W4_SPLIT": "0"}, {"IRE_PK": "0"}])
+                                 {"IRE_W4_FUSED_MINC": "100000", "IRE_ACT_SPLIT_MINC": "256"}, {"IRE_W4_FUSED_MINC": "100000"}, {"IRE_W4_SPLIT": "0"}, {"IRE_PK": "0"}, {"IRE_PK": "2"}])
 def test_alternate_kernel_schedules_agree(engine, weights0, env, monkeypatch):
     """Every A/B switch of the engine (conv_rb instead of conv_w4 at C >= 128, the 4-wave conv_w4, the v1 conv schedule, the
     v1 `up` kernel, the separate activation pass from C = 64, nearest x2 + 3x3 instead of the sub-pixel `up` convolution) computes the same network: each meets the oracle bound, and
@@ -124,13 +124,14 @@ def test_producer_consumer_c128_equals_conv_w4_bit_for_bit(engine, weights0, mon
     sc = _scores(imgs)
     base = engine.restore(imgs, scores=sc)
     _assert_close(base, onet.restore(imgs, sc, weights0))
-    monkeypatch.setenv("IRE_PK", "0")
-    alt_engine = Engine(device_index=0, max_batch=8)
-    try:
-        alt = alt_engine.restore(imgs, scores=sc)
-    finally:
-        alt_engine.close()
-    assert np.array_equal(alt, base), int(np.abs(alt.astype(np.int32) - base.astype(np.int32)).max())
+    for pk in ("0", "2"):          # conv_w4 for every C >= 128 conv | conv_pk for every one (the default: conv_pk where there is no residual)
+        monkeypatch.setenv("IRE_PK", pk)
+        alt_engine = Engine(device_index=0, max_batch=8)
+        try:
+            alt = alt_engine.restore(imgs, scores=sc)
+        finally:
+            alt_engine.close()
+        assert np.array_equal(alt, base), (pk, int(np.abs(alt.astype(np.int32) - base.astype(np.int32)).max()))
 
 
 @pytest.mark.parametrize("n,h,w", [(12, 32, 48), (20, 16, 32)])

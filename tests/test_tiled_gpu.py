@@ -73,6 +73,21 @@ def _rank(rank, world, port, h, w, q):
         out2 = tiled.restore_strip(sess, rows, scores[0], sharding, grouped=False, counter=cnt2)   # round 2's halo exchange + all-gather
         torch.cuda.synchronize()
         assert torch.equal(out, out2)
+        # two images in flight (tiled.restore_strips_pipelined): image B's op runs while image A's grouped exchange is on the wire;
+        # each image's strip must be the single-image flow's, bit for bit, and the exchange count is one per op and image
+        img_b = torch.from_numpy(synth.batch(1, h, w, start=78)[0]).cuda()
+        scores_b, _ = eng.classify_tensor(img_b[None], jp)
+        sess_b = eng.open_strips(h, w, world, rank, 1)
+        rows_b = tiled.split_rows(img_b, rank, world).contiguous()
+        single_b = tiled.restore_strip(sess_b, rows_b, scores_b[0], sharding).clone()
+        torch.cuda.synchronize()
+        cnt3 = {}
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        both = tiled.restore_strips_pipelined([sess, sess_b], [rows, rows_b], [scores[0], scores_b[0]], sharding, streams, counter=cnt3)
+        torch.cuda.synchronize()
+        assert torch.equal(both[0], out) and torch.equal(both[1], single_b)
+        assert cnt3["exchanges"] == 2 * cnt["exchanges"]
+        sess_b.close()
         ok = None
         if rank == 0:
             whole = eng.restore_tensor(img[None], scores=scores)[0]

@@ -16,7 +16,7 @@ def main(path):
         print("no stamps"); return
     t0 = min(rows[w][0][0] for w in wgs)
     us = lambda w, s: (rows[w][s][0] - t0) / 100.0
-    nit = max(k for w in wgs for k in rows[w] if 3 <= k <= 11) - 2
+    nit = max([k for w in wgs for k in rows[w] if 3 <= k <= 11] or [2]) - 2
     print("workgroups %d, items per workgroup %s" % (len(wgs), nit))
     def stat(name, v):
         v = np.asarray(v, dtype=float)
