@@ -295,7 +295,7 @@ int ire_init(const ire_config* cfg, ire_engine** out) {
     return guarded([&] {
         if (!cfg || !out) fail(IRE_ERR_INVALID_INPUT, "invalid arguments to ire_init");
         if (cfg->struct_size < sizeof(ire_config)) fail(IRE_ERR_INVALID_INPUT, "invalid ire_config.struct_size");
-        if (cfg->flags != 0) fail(IRE_ERR_INVALID_INPUT, "invalid ire_config.flags (reserved, must be 0)");
+        if (cfg->flags & ~(uint32_t)IRE_FLAG_RESULT_PNG_BASE64) fail(IRE_ERR_INVALID_INPUT, "invalid ire_config.flags (unknown bits set)");
         *out = nullptr;
         std::unique_ptr<ire_engine> E(new ire_engine());
         E->eng.reset(new Engine(*cfg));

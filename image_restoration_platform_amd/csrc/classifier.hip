@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void classifier_scan_kernel(const uint8_t* __r
                                                               unsigned long long* __restrict__ parts,
                                                               const uint8_t* __restrict__ is_jpeg,
                                                               double* __restrict__ scores, int32_t* __restrict__ label,
-                                                              float* __restrict__ cond) {
+                                                              float* __restrict__ cond,
+                                                              const float* __restrict__ film_w, const float* __restrict__ film_b, int film_n, float* __restrict__ film) {
     __shared__ ClsLds L;
     __shared__ unsigned long long red[4][CLS_NSUMS];
     __shared__ int s_last;
@@ -341,6 +342,7 @@ __global__ __launch_bounds__(256) void classifier_scan_kernel(const uint8_t* __r
         }
     }
     __syncthreads();
+    __shared__ float s_cond[8];
     if (tid == 0) {
         __hip_atomic_store(&tickets[img], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-cleaning: the next launch starts from zero without a memset
         uint64_t S[CLS_NSUMS];
@@ -351,9 +353,20 @@ __global__ __launch_bounds__(256) void classifier_scan_kernel(const uint8_t* __r
         for (int k = 0; k < 7; ++k) {
             if (scores) scores[(size_t)img * 7 + k] = sc[k];
             if (cond) cond[(size_t)img * 8 + k] = (float)sc[k];
+            s_cond[k] = (float)sc[k];
         }
         if (cond) cond[(size_t)img * 8 + 7] = 0.f;
         if (label) label[img] = lb;
+    }
+    if (film == nullptr) return;
+    // the restoration's FiLM vector of this image (Linear(7 -> film_n)(scores): gn.hip::film_kernel's arithmetic, term by term) from the
+    // same workgroup: a restore call that classifies inside needs no film launch and no kernel boundary behind the scan
+    __syncthreads();
+    for (int o = tid; o < film_n; o += 256) {
+        float acc = film_b[o];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) acc = __builtin_fmaf(film_w[o * 7 + k], s_cond[k], acc);
+        film[(size_t)img * film_n + o] = acc;
     }
 }
 
@@ -368,7 +381,7 @@ __global__ void scores_to_cond_kernel(const double* __restrict__ scores, int n, 
 
 void classifier_launch(const ClassifierTables& tb, const uint8_t* d_rgb, int n, int h, int w,
                        const uint8_t* d_is_jpeg, unsigned long long* d_sums, double* d_scores,
-                       int32_t* d_label, float* d_cond, hipStream_t stream) {
+                       int32_t* d_label, float* d_cond, hipStream_t stream, const float* d_film_w, const float* d_film_b, int film_n, float* d_film) {
     // d_sums (engine.cpp::ensure_io): [cap][14] sums | [cap] tickets (zero at allocation, reset by the kernel) | [cap][CLS_MAX_WG][14]
     // workgroup partials -- no memset, no second launch
     const int tiles_x = ceil_div(w, CT_W), tiles_y = ceil_div(h, CT_H);
@@ -379,7 +392,8 @@ void classifier_launch(const ClassifierTables& tb, const uint8_t* d_rgb, int n, 
     per_img = ceil_div(ntiles, ceil_div(ntiles, per_img));
     dim3 grid(per_img, n);
     hipLaunchKernelGGL(classifier_scan_kernel, grid, dim3(256), 0, stream, d_rgb, h, w, tiles_x, tiles_y,
-                       tb.lin16, tb.thr, tb.inv, d_sums, cls_tickets(d_sums), cls_parts(d_sums), d_is_jpeg, d_scores, d_label, d_cond);
+                       tb.lin16, tb.thr, tb.inv, d_sums, cls_tickets(d_sums), cls_parts(d_sums), d_is_jpeg, d_scores, d_label, d_cond,
+                       d_film_w, d_film_b, film_n, d_film);
     IRE_HIP(hipGetLastError());
 }
 

@@ -22,10 +22,12 @@ inline unsigned long long* cls_tickets(unsigned long long* sums) { return sums +
 inline unsigned long long* cls_parts(unsigned long long* sums) { return sums + (size_t)CLS_TICKET_CAP * 14 + CLS_TICKET_CAP; }
 
 // Asynchronous on `stream`: ONE launch -- scan, then the image's last workgroup reduces the partials and finalizes.
-// d_scores [n][7] double, d_label [n] int32, d_cond [n][8] float (any may be null).
+// d_scores [n][7] double, d_label [n] int32, d_cond [n][8] float (any may be null).  d_film != null: the image's last workgroup also
+// writes its FiLM vector d_film[n][film_n] = Linear(7 -> film_n)(scores) (gn.hip::film_kernel's arithmetic).
 void classifier_launch(const ClassifierTables& tb, const uint8_t* d_rgb, int n, int h, int w,
                        const uint8_t* d_is_jpeg, unsigned long long* d_sums, double* d_scores,
-                       int32_t* d_label, float* d_cond, hipStream_t stream);
+                       int32_t* d_label, float* d_cond, hipStream_t stream,
+                       const float* d_film_w = nullptr, const float* d_film_b = nullptr, int film_n = 0, float* d_film = nullptr);
 
 // Caller-supplied scores (ire_restore with scores != NULL) -> float conditioning vector.
 void scores_to_cond_launch(const double* d_scores, int n, float* d_cond, hipStream_t stream);

@@ -377,9 +377,7 @@ __global__ __launch_bounds__(DN_THREADS) void conv_down_kernel(ConvArgs a) {
 void conv_down_launch(const ConvArgs& a, hipStream_t stream) {
     if (a.cout % 64 || a.cout > 256 || a.nkc < 1 || a.stats == nullptr) fail(IRE_ERR_INTERNAL, "internal: conv_down shape");
     const int items = a.tiles_x * a.tiles_y * a.nimg * a.nblocks;
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = persistent_grid_cus();
     const int grid = items < cus ? items : cus;
     hipLaunchKernelGGL(conv_down_kernel, dim3(grid), dim3(DN_THREADS), 0, stream, a);
     IRE_HIP(hipGetLastError());

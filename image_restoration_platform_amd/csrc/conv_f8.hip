@@ -408,9 +408,7 @@ __global__ __launch_bounds__(F8_THREADS) void conv_f8_kernel(ConvArgs a) {
 void conv_f8_launch(bool resid, const ConvArgs& a, hipStream_t stream) {
     if (a.cout % 128 || a.cout > 256 || a.nkc < 2 || (a.nkc & 1) || !a.ab || !a.oscale || !a.stats) fail(IRE_ERR_INTERNAL, "internal: conv_f8 arguments");
     const int items = a.tiles_x * a.tiles_y * a.nimg * a.nblocks;
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = persistent_grid_cus();
     const int grid = items < cus ? items : cus;
     if (resid) hipLaunchKernelGGL(conv_f8_kernel<true>, dim3(grid), dim3(F8_THREADS), 0, stream, a);
     else hipLaunchKernelGGL(conv_f8_kernel<false>, dim3(grid), dim3(F8_THREADS), 0, stream, a);

@@ -26,7 +26,21 @@
 #define IRE_ST_PART 0
 #endif
 
+#include <cstdlib>
+
 namespace ire {
+
+// Workgroups a persistent convolution kernel launches at most: the device's CU count, or IRE_GRID_CUS when set (an A/B switch: with two
+// lanes -- two HIP streams restoring half a batch each -- grids of HALF the CUs let the two lanes' kernels co-reside, so that one lane's
+// dispatch gap, folded finalize, prologue and tail run beside the other lane's main loop instead of beside nothing).  Speed only: the
+// results do not depend on which workgroup ran which tile.
+inline int persistent_grid_cus() {
+    static const int forced = [] { const char* v = std::getenv("IRE_GRID_CUS"); return v ? std::atoi(v) : 0; }();
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return forced > 0 && forced < cus ? forced : cus;
+}
 
 enum { PRO_NONE = 0, PRO_GN = 1, PRO_U8 = 2 };
 

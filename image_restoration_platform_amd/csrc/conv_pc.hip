@@ -59,6 +59,10 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
                      // vs 260.5 / 259.8 us, RB2 313.9 / 317.2 vs 319.9 / 315.0 (same box): nothing -- the SIMD's vector issue is what the producers'
                      // transform and the epilogues fill (85 % busy: profiles/r02_experiments.md), not a wave's own speed.  Off.
 #endif
+#ifndef C3_INTERIOR
+#define C3_INTERIOR 0   // producers: tiles that touch no image border skip the zero-padding masks (two copies of the stage under a wave-uniform branch;
+                        // as a select hipcc if-converts it and the count goes up): 4 of ~70 vector instructions per chunk
+#endif
 #ifndef C3_ABL
 #define C3_ABL 0     // timing ablations (results wrong by design): 1 no transform, 2 no epilogue, 4 no MFMA loop, 8 no input loads, 16 no output stores, 32 no statistics, 64 no residual loads
 #endif
@@ -112,6 +116,11 @@ __device__ __forceinline__ float c3_swap16_add(float v) {       // see conv_rb.h
 // The per-stage barrier, spelled out: only LDS traffic has to be ordered (the tile a producer just wrote, the partials a consumer
 // just wrote); global loads and stores stay in flight across it.  (hipcc's __syncthreads() is the same two instructions on
 // gfx950 -- its workgroup-scope fence waits for lgkmcnt only -- measured equal; the asm form states the requirement.)
+__device__ __forceinline__ void c3_glds16(const void* gsrc, unsigned lds_dst_uniform) {   // LDS-DMA, 1 KB per wave-instruction (conv_rb.hip)
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
 __device__ __forceinline__ void c3_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int C, bool RESID, bool HEAD>
@@ -156,14 +165,21 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
     if (n_items == 0) return;
     const int n_stages = n_items * NKC;
     tl(0);
-    if (a.gn_stats) gn_fold(a, smem, cursor.first_img, cursor.last_img, 512);
+    {   // the weights (all of them, or the first slab of the streamed form) leave for LDS by DMA BEFORE the folded GroupNorm finalize: their
+        // fetch rides under its reduction (the finalize's scratch is the first 8 KB of the tile area, the weights sit behind both tiles)
+        const unsigned char* ws = reinterpret_cast<const unsigned char*>(a.w) + (K::STREAM ? (size_t)cursor.cur.it.nb * NKC * K::W_STAGE : 0);
+        const unsigned wl = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + K::W_OFF;
+        constexpr int PIECES = (K::STREAM ? 1 : NKC) * K::W_STAGE_CHUNKS / 64;                 // 1-KB pieces: 18 (C = 32), 72 (C = 64), 36 (streamed)
+        static_assert(((K::STREAM ? 1 : NKC) * K::W_STAGE_CHUNKS) % 64 == 0, "whole wave-instructions");
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        for (int p = wv; p < PIECES; p += THREADS / 64) c3_glds16(ws + ((size_t)p * 64 + lane) * 16, wl + p * 1024);
+    }
+    // the folded GroupNorm finalize writes this workgroup's coefficient table straight into LDS (and to global memory for nobody's benefit here)
+    if (a.gn_stats) gn_fold(a, smem, cursor.first_img, cursor.last_img, 512, reinterpret_cast<float2*>(smem + K::COEF_OFF));
     tl(1);
 
     {   // weights and bias stay in LDS for the whole kernel
         // resident weights: all of them; streamed: the slab of this workgroup's first stage (slot 0), the producers do the rest
-        const uint4* ws = reinterpret_cast<const uint4*>(a.w) + (K::STREAM ? (size_t)cursor.cur.it.nb * NKC * K::W_STAGE_CHUNKS : 0);
-        uint4* wd = reinterpret_cast<uint4*>(smem + K::W_OFF);
-        for (int i = tid; i < (K::STREAM ? 1 : NKC) * K::W_STAGE_CHUNKS; i += THREADS) wd[i] = ws[i];
         if (tid < C) reinterpret_cast<float*>(smem + K::BIAS_OFF)[tid] = a.bias[tid];
         if constexpr (C == 64) { if (tid == 0) *reinterpret_cast<unsigned*>(smem + K::CNT_OFF) = 0u; }
         // the GroupNorm+FiLM coefficients of the images this workgroup's items belong to (gn_fold just wrote them, or
@@ -171,8 +187,9 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
         const int nim = cursor.last_img - cursor.first_img + 1;                // <= COEF_IMGS (conv_pc_launch checks nimg)
         const float2* ab = a.ab + (size_t)cursor.first_img * C;
         float2* cd = reinterpret_cast<float2*>(smem + K::COEF_OFF);
-        for (int i = tid; i < nim * C; i += THREADS) cd[i] = ab[i];
+        if (!a.gn_stats) for (int i = tid; i < nim * C; i += THREADS) cd[i] = ab[i];      // (gn_finalize_kernel ran: row strips, IRE_GN_FOLD=0)
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's weight pieces are in LDS
     __syncthreads();
     tl(2);
 
@@ -197,7 +214,7 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
             lds_off[i] = (p * 4 + (c8 ^ ((p >> 2) & 3))) * 16;
         }
         uint4 R[P_ITERS];
-        unsigned okm[P_ITERS];         // all ones / zero: the chunk in R[i] lies inside the image (travels with the data)
+        unsigned okbits = 0;           // bit i: the chunk in R[i] lies inside the image (travels with the data; one register, not one mask per chunk)
         float cA[8], cB[8];
         // raw rows of stage `ls` (item, 32-channel slice), requested chunk by chunk (load_chunk), and its coefficients (from LDS)
         PersistStage ls = cursor.cur;
@@ -218,7 +235,7 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
                 const u32x4_t lv = __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, IRE_LD_IN);
                 R[i] = make_uint4(lv.x, lv.y, lv.z, lv.w);
             }
-            okm[i] = ok ? 0xffffffffu : 0u;
+            okbits = (okbits & ~(1u << i)) | (ok ? (1u << i) : 0u);
         };
         auto load_coeffs = [&](const PersistStage& st) __attribute__((always_inline)) {      // (A, B) of this thread's 8 channels
             const float4* ab = reinterpret_cast<const float4*>(smem + K::COEF_OFF) + ((st.it.img - cursor.first_img) * C + st.kc * 32 + c8 * 8) / 2;
@@ -253,7 +270,8 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
                 if constexpr (2 * p + 1 < 9) reinterpret_cast<uint4*>(wslot)[tp + (2 * p + 1) * C3_PROD] = vb;
             }
         };
-        auto transform_stage = [&](unsigned char* tile, unsigned char* wslot) __attribute__((always_inline)) {
+        auto transform_stage_v = [&](unsigned char* tile, unsigned char* wslot, auto interior_tag) __attribute__((always_inline)) {
+            constexpr bool INTERIOR = decltype(interior_tag)::value;
             w_issue(std::integral_constant<int, 0>{}); w_issue(std::integral_constant<int, 1>{});
             auto pair = [&](auto pp_tag) __attribute__((always_inline)) {
                 constexpr int pp_ = decltype(pp_tag)::value, i = 2 * pp_;
@@ -319,8 +337,11 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
                 }
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
-                    const unsigned m = okm[i + k];                                     // zero padding applies AFTER the activation
-                    const uint4 ov = make_uint4(o[4 * k] & m, o[4 * k + 1] & m, o[4 * k + 2] & m, o[4 * k + 3] & m);
+                    uint4 ov = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+                    if constexpr (!INTERIOR) {
+                        const unsigned m = (okbits >> (i + k)) & 1u ? 0xffffffffu : 0u;   // zero padding applies AFTER the activation
+                        ov = make_uint4(o[4 * k] & m, o[4 * k + 1] & m, o[4 * k + 2] & m, o[4 * k + 3] & m);
+                    }
                     *reinterpret_cast<uint4*>(tile + lds_off[i + k]) = ov;
                 }
                 load_chunk(i);
@@ -331,6 +352,18 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
             };
             pair(std::integral_constant<int, 0>{}); pair(std::integral_constant<int, 1>{}); pair(std::integral_constant<int, 2>{});
             if constexpr (P_ITERS > 6) { pair(std::integral_constant<int, 3>{}); pair(std::integral_constant<int, 4>{}); }
+        };
+        // chunk slots past the tile (halo-tile row 18: only the last chunk of the upper threads) are never read: they do not count against "interior"
+        unsigned past_last = 0u;
+        {
+            const int q = tp + (P_ITERS - 1) * PROD;
+            past_last = (q >> 2) >= C3_IH * C3_IW ? (1u << (P_ITERS - 1)) : 0u;
+        }
+        auto transform_stage = [&](unsigned char* tile, unsigned char* wslot) __attribute__((always_inline)) {
+            if constexpr (C3_INTERIOR) {
+                if (__builtin_amdgcn_ballot_w64((okbits | past_last) != (1u << P_ITERS) - 1u) == 0) { transform_stage_v(tile, wslot, std::true_type{}); return; }
+            }
+            transform_stage_v(tile, wslot, std::false_type{});
         };
         // stage 0 -> R; then every transform reloads R with the stage after (past the last stage the cursor stays on it: a
         // redundant reload of rows that are never used).  `ps` = the stage whose rows are in R = the stage being produced.
@@ -841,9 +874,7 @@ bool conv_pc_fits(int C, int tiles_per_img, int nimg) {
     // the workgroups of XCD group x walk items [items x / X, items (x + 1) / X) (persist.hpp): images spanned by a range
     const int nblk = C < 64 ? 1 : C / 64;
     const long long ipi = (long long)tiles_per_img * nblk, items = ipi * nimg;
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = persistent_grid_cus();
     const long long G = items < cus ? items : cus, X = G < 8 ? G : 8;
     for (long long x = 0; x < X; ++x) {
         const long long lo = items * x / X, hi = items * (x + 1) / X;
@@ -859,9 +890,7 @@ void conv_pc_launch(bool resid, bool head, const ConvArgs& a, hipStream_t stream
     if (head ? (C != 32 || !a.u8_in || !a.u8_out) : !a.stats) fail(IRE_ERR_INTERNAL, "internal: conv_pc arguments");
     if (!conv_pc_fits(C, a.tiles_x * a.tiles_y, a.nimg)) fail(IRE_ERR_INTERNAL, "internal: conv_pc batch");
     const int items = a.tiles_x * a.tiles_y * a.nimg * a.nblocks;
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = persistent_grid_cus();
     const int grid = items < cus ? items : cus;
 #define PC_GO(CC, RS, HD) hipLaunchKernelGGL((conv_pc_kernel<CC, RS, HD>), dim3(grid), dim3(C3_CONS + pc_prod(CC, HD)), 0, stream, a)
     if (head) PC_GO(32, false, true);

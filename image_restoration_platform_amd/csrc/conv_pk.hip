@@ -234,7 +234,7 @@ __global__ __launch_bounds__(PK_THREADS) void conv_pk_kernel(ConvArgs a) {
         q3 = cursor.next();
     }
     tl(0);
-    if (a.gn_stats) gn_fold(a, smem, cursor.first_img, cursor.last_img, 512);
+    if (a.gn_stats) gn_fold(a, smem, cursor.first_img, cursor.last_img, 512, reinterpret_cast<float2*>(smem + PK_COEF_BASE));     // the coefficient table, straight into LDS
     tl(1);
     {
         if (tid < C) reinterpret_cast<float*>(smem + PK_BIAS_BASE)[tid] = a.bias[tid];
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(PK_THREADS) void conv_pk_kernel(ConvArgs a) {
         const int nim = cursor.last_img - cursor.first_img + 1;                // <= PK_IMGS (conv_pk_fits)
         const float2* ab = a.ab + (size_t)cursor.first_img * C;
         float2* cd = reinterpret_cast<float2*>(smem + PK_COEF_BASE);
-        for (int i = tid; i < nim * C; i += PK_THREADS) cd[i] = ab[i];
+        if (!a.gn_stats) for (int i = tid; i < nim * C; i += PK_THREADS) cd[i] = ab[i];      // (gn_finalize_kernel ran: row strips, IRE_GN_FOLD=0)
     }
     __syncthreads();
 
@@ -624,9 +624,7 @@ bool conv_pk_fits(int C, int tiles_per_img, int nimg) {
     if (C != 128 && C != 256) return false;
     if (nimg <= PK_IMGS) return true;
     const long long ipi = (long long)tiles_per_img * (C / PK_NT), items = ipi * nimg;
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = persistent_grid_cus();
     const long long G = items < cus ? items : cus, X = G < 8 ? G : 8;
     for (long long x = 0; x < X; ++x) {
         const long long lo = items * x / X, hi = items * (x + 1) / X;
@@ -643,9 +641,7 @@ void conv_pk_launch(bool resid, const ConvArgs& a, hipStream_t stream) {
         fail(IRE_ERR_INTERNAL, "internal: conv_pk arguments");
     if (!conv_pk_fits(C, a.tiles_x * a.tiles_y, a.nimg)) fail(IRE_ERR_INTERNAL, "internal: conv_pk batch");
     const int items = a.tiles_x * a.tiles_y * a.nimg * a.nblocks;
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = persistent_grid_cus();
     const int grid = items < cus ? items : cus;
 #define PK_GO(CC, RS) hipLaunchKernelGGL((conv_pk_kernel<CC, RS>), dim3(grid), dim3(PK_THREADS), 0, stream, a)
     if (C == 128) { if (resid) PK_GO(128, true); else PK_GO(128, false); }

@@ -655,9 +655,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
 template <int NT, bool RESID, bool WRES, bool FUSED_ACT, int DBG = 0, bool UPS = false, bool HEAD = false>
 void launch_rb(const ConvArgs& a, hipStream_t stream) {
     const int items = a.tiles_x * a.tiles_y * a.nimg * a.nblocks;
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = persistent_grid_cus();
     // one workgroup per CU; with 8-row tiles (256 threads) two independent workgroups per CU where their LDS fits
     const int per_cu = (RB_TH == 8 && RbCfg<NT, RESID, WRES, FUSED_ACT>::LDS_BYTES <= 80 * 1024) ? 2 : 1;
     const int grid = items < cus * per_cu ? items : cus * per_cu;

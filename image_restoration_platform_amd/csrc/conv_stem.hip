@@ -189,9 +189,7 @@ __global__ __launch_bounds__(ST_THREADS) void conv_stem_kernel(ConvArgs a) {
 void conv_stem_launch(const ConvArgs& a, hipStream_t stream) {
     if (a.cout != 32 || a.Hout != a.Hin || a.Wout != a.Win || !a.stats) fail(IRE_ERR_INTERNAL, "internal: conv_stem shape");
     const int items = a.tiles_x * a.tiles_y * a.nimg;
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = persistent_grid_cus();
     const int grid = items < 2 * cus ? items : 2 * cus;
     hipLaunchKernelGGL(conv_stem_kernel, dim3(grid), dim3(ST_THREADS), 0, stream, a);
     IRE_HIP(hipGetLastError());

@@ -622,9 +622,7 @@ void conv_up_subpixel_launch(const ConvArgs& a, hipStream_t stream) {
     if (a.nkc < 2 || (a.nkc & 1) || a.cout > 256) fail(IRE_ERR_INTERNAL, "internal: conv_up_subpixel shape");
     if (a.in1 && (!a.w1 || !a.stats || (a.cout != 32 && a.cout != 64 && a.cout != 128))) fail(IRE_ERR_INTERNAL, "internal: fused conv_up arguments");
     const int items = a.tiles_x * a.tiles_y * a.nimg * a.nblocks;
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = persistent_grid_cus();
     const int grid = items < cus ? items : cus;
     if (!a.in1) hipLaunchKernelGGL(conv_up_kernel<0>, dim3(grid), dim3(UP_THREADS), 0, stream, a);
     else if (a.cout == 32) hipLaunchKernelGGL(conv_up_kernel<2>, dim3(grid), dim3(UP_THREADS), 0, stream, a);

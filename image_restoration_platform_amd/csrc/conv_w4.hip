@@ -131,13 +131,6 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
 #ifdef IRE_W4_TL
     if (a.stamps && tid == 0) { a.stamps[(size_t)blockIdx.x * 32] = __builtin_amdgcn_s_memrealtime(); a.stamps[(size_t)blockIdx.x * 32 + 1] = __builtin_amdgcn_s_memtime(); }
 #endif
-    if (a.gn_stats) gn_fold(a, smem, cursor.first_img, cursor.last_img);     // GroupNorm finalize of the input tensor, folded in (gn_fold.hpp)
-#ifdef IRE_W4_TL
-    if (a.stamps && tid == 0) {
-        a.stamps[(size_t)blockIdx.x * 32 + 2] = __builtin_amdgcn_s_memrealtime(); a.stamps[(size_t)blockIdx.x * 32 + 3] = __builtin_amdgcn_s_memtime();
-        a.stamps[(size_t)blockIdx.x * 32 + 26] = __builtin_amdgcn_s_getreg((31 << 11) | 20); a.stamps[(size_t)blockIdx.x * 32 + 27] = (unsigned long long)my_items;
-    }
-#endif
     using StageInfo = PersistStage;
     StageInfo sq0 = cursor.cur, sq1 = cursor.next(), sq2 = cursor.next();
 
@@ -740,7 +733,10 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
         par ^= 1;
     };
 
-    // ---- prologue: stage 0 input + slab -> LDS directly; slab of stage 1 by copy as well; R <- stage 1 input --------------
+    // ---- prologue: the first stage's raw rows (registers) and the first two weight slabs (LDS-DMA) are requested BEFORE the folded
+    // GroupNorm finalize -- neither needs its result, and its scratch (the first 8 KB of input tile 0) is not where they land -- so their
+    // fetch rides under its reduction (round 4 timelines: finalize 3.2 us + 7 us of dependent prologue loads per launch, serialised);
+    // behind it: coefficients, stage 0 -> tile 0, R <- stage 1
     {
         float* bl = reinterpret_cast<float*>(smem + C::MAIN_BYTES + C::RED_BYTES);
         if (tid < a.cout && tid < 256) bl[tid] = a.bias[tid];
@@ -750,11 +746,26 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
         }
         item_offsets(sq0.it);        // stages 0, 1, 2 belong to one item (nkc >= 8)
         load_stage(sq0, R);
+        {
+            const unsigned char* ws0 = wslab(sq0);
+            const unsigned char* ws1 = wslab(sq1);
+            const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+            for (int p = wave_u; p < C::W_CHUNKS / 64; p += WAVES) {
+                w4_glds16(ws0 + ((size_t)p * 64 + lane) * 16, smem_lds + C::W_BASE + p * 1024);
+                w4_glds16(ws1 + ((size_t)p * 64 + lane) * 16, smem_lds + C::W_BASE + C::W_BYTES + p * 1024);
+            }
+        }
+        if (a.gn_stats) gn_fold(a, smem, cursor.first_img, cursor.last_img);     // GroupNorm finalize of the input tensor, folded in (gn_fold.hpp)
+#ifdef IRE_W4_TL
+        if (a.stamps && tid == 0) {
+            a.stamps[(size_t)blockIdx.x * 32 + 2] = __builtin_amdgcn_s_memrealtime(); a.stamps[(size_t)blockIdx.x * 32 + 3] = __builtin_amdgcn_s_memtime();
+            a.stamps[(size_t)blockIdx.x * 32 + 26] = __builtin_amdgcn_s_getreg((31 << 11) | 20); a.stamps[(size_t)blockIdx.x * 32 + 27] = (unsigned long long)my_items;
+        }
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // R and this wave's slab pieces have landed
+#pragma unroll
+        for (int i = 0; i < C::IN_ITERS; ++i) asm volatile("" : "+v"(R.v[i]));
         if constexpr (FUSED) stage_coeffs(fetch_coeffs(sq0));
-        const uint4* ws0 = reinterpret_cast<const uint4*>(wslab(sq0));
-        const uint4* ws1 = reinterpret_cast<const uint4*>(wslab(sq1));
-        uint4* wd = reinterpret_cast<uint4*>(smem + C::W_BASE);
-        for (int i = tid; i < C::W_CHUNKS; i += C::THREADS) { wd[i] = ws0[i]; wd[C::W_CHUNKS + i] = ws1[i]; }
         uint4* in0 = reinterpret_cast<uint4*>(smem);
 #pragma unroll
         for (int i = 0; i < C::IN_ITERS; ++i) store_chunk(i, R, in0);
@@ -787,9 +798,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_w4_kernel(ConvArgs a) {
 template <int NT, int WAVES, bool RESID, bool UPS, int DBG = 0, bool FUSED = false, bool FP8 = false>
 void launch_w4(const ConvArgs& a, hipStream_t stream) {
     const int items = a.tiles_x * a.tiles_y * a.nimg * a.nblocks;
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = persistent_grid_cus();
     const int grid = items < cus ? items : cus;
     hipLaunchKernelGGL((conv_w4_kernel<NT, WAVES, RESID, UPS, DBG, FUSED, FP8>), dim3(grid), dim3(WAVES * 64), 0, stream, a);
     IRE_HIP(hipGetLastError());

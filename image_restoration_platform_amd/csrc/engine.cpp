@@ -1160,13 +1160,16 @@ void Engine::restore_device(const uint8_t* d_rgb, int n, int h, int w, const dou
     if (d_scores) {
         scores_to_cond_launch(d_scores, n, d_cond_, stream);
     } else {
+        // classified inside: the scan's last workgroup per image writes the FiLM vector too (no film launch, no boundary behind the scan)
         prof_begin(FAM_CLASSIFIER, stream, 0, (double)n * h * w * 3);
-        classifier_launch(tables_, d_rgb, n, h, w, d_is_jpeg, d_sums_, d_scores_, d_label_, d_cond_, stream);
+        classifier_launch(tables_, d_rgb, n, h, w, d_is_jpeg, d_sums_, d_scores_, d_label_, d_cond_, stream, net_.d_film_w, net_.d_film_b, kFilmDim, d_film_);
         prof_end(stream);
     }
-    prof_begin(FAM_GN, stream, 0, 0);
-    film_launch(d_cond_, n, net_.d_film_w, net_.d_film_b, kFilmDim, d_film_, stream);
-    prof_end(stream);
+    if (d_scores) {
+        prof_begin(FAM_GN, stream, 0, 0);
+        film_launch(d_cond_, n, net_.d_film_w, net_.d_film_b, kFilmDim, d_film_, stream);
+        prof_end(stream);
+    }
     last_n_ = n;
     batches_run_ += 1; images_restored_ += n; last_batch_ = n;
     {

@@ -50,7 +50,7 @@ def test_invalid_config_is_reported_not_crashed():
     assert b"invalid" in lib.ire_last_error()
     assert lib.ire_init(None, ctypes.byref(h)) == _lib.IRE_ERR_INVALID_INPUT
     cfg.struct_size = ctypes.sizeof(_lib.IreConfig)
-    cfg.flags = 1         # reserved: must be 0 (checked before any device is touched)
+    cfg.flags = 2         # an unknown flag bit (bit 0 = IRE_FLAG_RESULT_PNG_BASE64): rejected before any device is touched
     assert lib.ire_init(ctypes.byref(cfg), ctypes.byref(h)) == _lib.IRE_ERR_INVALID_INPUT
     assert b"flags" in lib.ire_last_error()
     assert lib.ire_profile_report(None, None, 0, None) == _lib.IRE_ERR_INVALID_INPUT

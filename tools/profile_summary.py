@@ -29,7 +29,7 @@ def stats(src, dst, title, footer=""):
 def is_conv3x3(name):
     if "conv_rb_kernel" in name or "conv_pc_kernel" in name:   # the HEAD instantiation (last template argument true) is its own family
         return not name.rstrip().endswith(", true>(ire::ConvArgs)")
-    if "conv_w4_kernel" in name or "conv_up_kernel" in name or "conv_down_kernel" in name or "conv_f8_kernel" in name:
+    if "conv_w4_kernel" in name or "conv_up_kernel" in name or "conv_down_kernel" in name or "conv_f8_kernel" in name or "conv_pk_kernel" in name:
         return True
     if "conv_mfma_kernel<4, 9," in name and not name.rstrip().endswith("true>(ire::ConvArgs)"):   # last arg = HEAD: its own family
         return True
@@ -52,6 +52,9 @@ def group_of(name, k):
     The step's op order is fixed (engine.cpp::build_program): enc0..3, mid, dec2..0; the C >= 128 kernels serve level 2
     (enc2, dec2) and level 3 (enc3, mid) with ONE instantiation each, so the position in the step tells the level."""
     n = name.rstrip()
+    if "conv_pk_kernel<" in n:          # conv_pk_kernel<C, RESID>: the width is the level
+        args = n[n.find("<") + 1:n.find(">")].replace(" ", "").split(",")
+        return "L%d.rb%d" % ({"128": 2, "256": 3}[args[0]], 2 if args[1] == "true" else 1)
     if "conv_w4_kernel" in n or "conv_f8_kernel" in n:
         resid = "<128, 8, true" in n or n.startswith("void ire::(anonymous namespace)::conv_f8_kernel<true") or "conv_f8_kernel<true" in n
         lvl = [2, 2, 3, 3, 3, 3, 2, 2][k % 8]
