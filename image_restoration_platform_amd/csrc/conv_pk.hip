@@ -44,6 +44,12 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #ifndef PK_DMA_SPLIT
 #define PK_DMA_SPLIT 1   // 1: three slab DMA pieces in front of the first transform group, six behind it; 0: all nine at the top of the stage
 #endif
+#ifndef PK_BDEPTH
+#define PK_BDEPTH 2  // weight-fragment registers of the consumers' rotation: 2 = the next fragment is read one MFMA pair ahead, 3 = two pairs ahead
+#endif
+#ifndef PK_CPRIO
+#define PK_CPRIO 0   // 1: consumers raise their priority early in a stage (k-steps 0..3: 3, 4..6: 2, 7..8: 1 -- conv_w4's progress feedback: the wave that is behind outranks its partner)
+#endif
 #ifndef PK_DBUF
 #define PK_DBUF 0    // 1: two producer register sets, a stage's rows requested two stages ahead; 0: one set, one stage ahead (vmcnt(0) at the top of a stage)
 #endif
@@ -67,7 +73,7 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
                      // requested a whole pass ahead (pass 1 at the epilogue's start, pass 2 behind pass 0, pass 3 behind pass 1)
 #endif
 #ifndef PK_ABL
-#define PK_ABL 0     // timing ablations (results wrong by design): 1 no transform, 2 no epilogue, 4 no MFMA loop, 8 no slab DMA
+#define PK_ABL 0     // timing ablations (results wrong by design): 1 no transform, 2 no epilogue, 4 no MFMA loop, 8 no slab DMA, 16 epilogue without its global stores
 #endif
 
 constexpr int PK_CONS = 512, PK_PROD = 256, PK_THREADS = PK_CONS + PK_PROD;
@@ -471,20 +477,27 @@ __global__ __launch_bounds__(PK_THREADS) void conv_pk_kernel(ConvArgs a) {
                     const int ky = st / 3, kx = st - ky * 3;
                     return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ib + ((m + ky) * PK_IW + kx) * 16));
                 };
-                bf16x8_t bq[2], aq[2][2];
-                bq[0] = rd_b(0, 0); aq[0][0] = rd_a(0, 0); aq[0][1] = rd_a(0, 1);
+                constexpr int BD = PK_BDEPTH;                      // weight-fragment registers in rotation
+                constexpr int NG = 9 * NTL;                        // weight fragments (= MFMA pairs) of a stage
+                auto rd_bg = [&](int g) __attribute__((always_inline)) -> bf16x8_t { return rd_b(g / NTL, g % NTL); };
+                bf16x8_t bq[BD], aq[2][2];
+#pragma unroll
+                for (int d = 0; d + 1 < BD; ++d) bq[d] = rd_bg(d);
+                aq[0][0] = rd_a(0, 0); aq[0][1] = rd_a(0, 1);
 #pragma unroll
                 for (int st = 0; st < 9; ++st)
 #pragma unroll
                     for (int j = 0; j < NTL; ++j) {
                         const int g = st * NTL + j;
-                        if (j + 1 < NTL) bq[(g + 1) & 1] = rd_b(st, j + 1);
-                        else if (st + 1 < 9) bq[(g + 1) & 1] = rd_b(st + 1, 0);
+                        if (PK_CPRIO && j == 0 && st == 0) __builtin_amdgcn_s_setprio(3);
+                        if (PK_CPRIO && j == 0 && st == 4) __builtin_amdgcn_s_setprio(2);
+                        if (PK_CPRIO && j == 0 && st == 7) __builtin_amdgcn_s_setprio(1);
+                        if (g + BD - 1 < NG) bq[(g + BD - 1) % BD] = rd_bg(g + BD - 1);
                         if (st + 1 < 9 && j == 1) aq[(st + 1) & 1][0] = rd_a(st + 1, 0);
                         if (st + 1 < 9 && j == 2) aq[(st + 1) & 1][1] = rd_a(st + 1, 1);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int m = 0; m < 2; ++m) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[g & 1], aq[st & 1][m], acc[m][j], 0, 0, 0);   // D[cout][pixel]
+                        for (int m = 0; m < 2; ++m) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[g % BD], aq[st & 1][m], acc[m][j], 0, 0, 0);   // D[cout][pixel]
                         __builtin_amdgcn_sched_barrier(0);
                     }
             }
@@ -594,7 +607,8 @@ __global__ __launch_bounds__(PK_THREADS) void conv_pk_kernel(ConvArgs a) {
                         const bool ok = trow[m] && tcol0 + 16 * q + 4 * k < a.Wout;
                         ssum += ok ? s1 : 0.f; qsum += ok ? q1 : 0.f;
                         const u32x4_t o4 = {w[0], w[1], w[2], w[3]};
-                        __builtin_amdgcn_raw_buffer_store_b128(o4, orsrc, ok ? toffs[m] + (unsigned)(4 * q + k) * cstep : 0xffffffffu, 0, IRE_ST_LINE);
+                        if constexpr (PK_ABL & 16) asm volatile("" :: "v"(o4));
+                        else __builtin_amdgcn_raw_buffer_store_b128(o4, orsrc, ok ? toffs[m] + (unsigned)(4 * q + k) * cstep : 0xffffffffu, 0, IRE_ST_LINE);
                     }
                     if constexpr (RESID && PK_RDMA) { if (2 * m + q + 2 < 4) load_resid_pass(2 * m + q + 2, rvt[(2 * m + q) & 1]); }      // pass p + 2 into the set pass p (or nobody) used
                     else if constexpr (RESID) { if (2 * m + q + PK_RING < 4) load_resid_pass(2 * m + q + PK_RING, rvt[(2 * m + q) % PK_RING]); }
