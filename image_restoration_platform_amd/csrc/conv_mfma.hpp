@@ -92,7 +92,6 @@ struct ConvArgs {
     int iy_lo, iy_span;
     int fp8;                     // conv_w4: OCP e4m3 operands (a.w = fp8 slabs, a.bias = bias / oscale)
     const float* oscale;         // fp8: [cout] accumulator -> output scale (weight scale of the channel / activation scale)
-    int w4_waves;                // conv_w4 on a pre-activated input (ab == nullptr): 8 (default) or 4 waves per workgroup
     int w4_nt;                   // conv_w4 cout block: 128 (default, 0) or 64 (launches whose 128-cout items would leave CUs idle; a.w = the 64-cout slabs)
     unsigned long long* stamps;  // diagnostic builds only (IRE_RB_ABLATE, DBG bit 16): s_memtime stamps, else null
 };

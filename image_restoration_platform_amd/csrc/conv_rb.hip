@@ -251,7 +251,7 @@ __global__ __launch_bounds__(RB_THREADS) void conv_rb_kernel(ConvArgs a) {
             const f32x2_t sv = y * rinv;
             return rb_pack(sv.x, sv.y);
         } else {
-            return w;                                  // input was activated by gn_apply_silu (gn.hip)
+            return w;                                  // the input carries no GroupNorm (the `up` / `down` inputs of this family)
         }
     };
     auto store_words = [&](int i, const RbRegs& R, const unsigned (&tw)[4], uint4* lds_in) {

@@ -11,8 +11,9 @@
 //
 // Stage = 16 input channels (pixel = 2 x 16-B chunks in the LDS tile): 9 k-steps (one per tap) x 16 MFMAs = 144
 // MFMAs per wave = 4608 pipe cycles.  LDS: 2 x (19.6 KB input tile + 36.9 KB weight slab [tap][c8][128][8]).
-// Pipeline, VMEM ordering rules, LDS-DMA weights, stage queue: as conv_rb.hip.  The input must already be
-// activated (gn_apply_silu): plain copy while staging.  Epilogue: the 128-channel tile leaves in 4 passes of 32
+// Pipeline, VMEM ordering rules, LDS-DMA weights, stage queue: as conv_rb.hip.  The engine launches the
+// fused-activation 8-wave form (GroupNorm+FiLM+SiLU while staging); the plain-copy staging of a pre-activated input and the
+// 4-wave form are template branches no launch instantiates since round 4.  Epilogue: the 128-channel tile leaves in 4 passes of 32
 // channels through the current stage buffer (bias, residual, GroupNorm partials, full-line stores).
 #include "conv_mfma.hpp"
 #include "persist.hpp"
@@ -808,32 +809,16 @@ void launch_w4(const ConvArgs& a, hipStream_t stream) {
 
 // a.nkc = Cin/16 stages, a.nblocks = cout/128, a.w = slabs [nblock][kc16][tap][c8][128][8], tiles of 16x32.
 void conv_w4_launch(bool resid, const ConvArgs& a, hipStream_t stream) {
-#ifdef IRE_W4_STAMPS
-    static const int dbg = std::getenv("IRE_W4_DBG") ? std::atoi(std::getenv("IRE_W4_DBG")) : 0;
-    switch (dbg) {
-        case 1: return launch_w4<128, 4, false, false, 1>(a, stream);
-        case 2: return launch_w4<128, 4, false, false, 2>(a, stream);
-        case 8: return launch_w4<128, 4, false, false, 8>(a, stream);
-        case 32: return launch_w4<128, 4, false, false, 32>(a, stream);
-        case 40: return launch_w4<128, 4, false, false, 40>(a, stream);
-        case 42: return launch_w4<128, 4, false, false, 42>(a, stream);
-        case 46: return launch_w4<128, 4, false, false, 46>(a, stream);
-        case 4: return launch_w4<128, 4, false, false, 4>(a, stream);
-        default: break;
-    }
-#endif
-    // fused activation (a.ab) exists in the 8-wave form only: the 4-wave form is for pre-activated inputs (engine.cpp passes
-    // a.w4_waves = 4 only then); asking for it with coefficients would silently skip GroupNorm+SiLU, so refuse
+    // the engine launches the 8-wave form with the activation fused into the staging (the 4-wave form and the pre-activated input
+    // it needed lost every A/B from round 1 to round 3; their launches were removed in round 4)
+    if (a.ab == nullptr) fail(IRE_ERR_INTERNAL, "internal: conv_w4 needs the GroupNorm coefficients of its input");
     if (a.fp8) {
-        if (a.ab == nullptr || a.oscale == nullptr) fail(IRE_ERR_INTERNAL, "internal: fp8 conv_w4 needs the fused activation and the per-channel scales");
+        if (a.oscale == nullptr) fail(IRE_ERR_INTERNAL, "internal: fp8 conv_w4 needs the per-channel scales");
         if (resid) launch_w4<128, 8, true, false, 0, true, true>(a, stream); else launch_w4<128, 8, false, false, 0, true, true>(a, stream);
         return;
     }
-    if (a.w4_waves == 4 && a.ab != nullptr) fail(IRE_ERR_INTERNAL, "internal: conv_w4 4-wave form has no fused activation");
-    if (a.w4_waves == 4) { if (resid) launch_w4<128, 4, true, false>(a, stream); else launch_w4<128, 4, false, false>(a, stream); }
-    else if (a.ab != nullptr && a.w4_nt == 64) { if (resid) launch_w4<64, 8, true, false, 0, true>(a, stream); else launch_w4<64, 8, false, false, 0, true>(a, stream); }
-    else if (a.ab != nullptr) { if (resid) launch_w4<128, 8, true, false, 0, true>(a, stream); else launch_w4<128, 8, false, false, 0, true>(a, stream); }
-    else            { if (resid) launch_w4<128, 8, true, false>(a, stream); else launch_w4<128, 8, false, false>(a, stream); }
+    if (a.w4_nt == 64) { if (resid) launch_w4<64, 8, true, false, 0, true>(a, stream); else launch_w4<64, 8, false, false, 0, true>(a, stream); }
+    else { if (resid) launch_w4<128, 8, true, false, 0, true>(a, stream); else launch_w4<128, 8, false, false, 0, true>(a, stream); }
 }
 
 }  // namespace ire

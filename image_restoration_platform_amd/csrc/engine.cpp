@@ -85,12 +85,9 @@ Engine::Engine(const ire_config& cfg) {
     if (cfg.flags & ~(uint32_t)IRE_FLAG_RESULT_PNG_BASE64) fail(IRE_ERR_INVALID_INPUT, "invalid ire_config.flags (unknown bits set)");
     flags_ = cfg.flags;
     if (const char* v = std::getenv("IRE_CONV_V1")) rb_tile_h_ = (v[0] == '1') ? 8 : kRbTileH;
-    if (const char* v = std::getenv("IRE_ACT_SPLIT_MINC")) act_split_min_c_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_RB_PRIO")) prio_young_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_W4")) use_w4_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_W4_SPLIT")) w4_split_ = std::atoi(v);
-    if (const char* v = std::getenv("IRE_W4_WAVES")) w4_waves_ = std::atoi(v) == 4 ? 4 : 8;
-    if (const char* v = std::getenv("IRE_W4_FUSED_MINC")) w4_fused_min_c_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_UP_RB_MINC")) up_rb_min_c_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_UP_SUBPIX")) up_subpixel_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_UP_FUSE")) up_fuse_ = std::atoi(v);
@@ -679,7 +676,6 @@ void Engine::free_workspace() {
     for (auto& L : lanes_) {
         std::memset(L.act, 0, sizeof(L.act));
         std::memset(L.skip, 0, sizeof(L.skip));
-        std::memset(L.actbuf, 0, sizeof(L.actbuf));
         L.stats = L.stats2 = nullptr;
         L.ab = nullptr;
     }
@@ -692,7 +688,7 @@ size_t Engine::bytes_per_image(int h, int w) const {
     size_t b = 0;
     for (int l = 0; l < 4; ++l) {
         const size_t t = (size_t)(h >> l) * (w >> l) * kWidths[l] * 2;
-        b += t * (4 + (l < 3 ? 1 : 0) + (kWidths[l] >= act_split_min_c_ ? 1 : 0));
+        b += t * (4 + (l < 3 ? 1 : 0));
     }
     b += 2 * (size_t)ceil_div(h, 4) * ceil_div(w, 32) * 16 * 4 + 256 * sizeof(float2);
     b += (size_t)h * w * 3 * 2;      // d_in_ / d_out_
@@ -723,7 +719,6 @@ void Engine::ensure_workspace(int n, int h, int w) {
                 const size_t bytes = (size_t)per * (h >> l) * (w >> l) * kWidths[l] * 2;
                 for (int b = 0; b < 4; ++b) L.act[l][b] = (unsigned short*)alloc(bytes);
                 if (l < 3) L.skip[l] = (unsigned short*)alloc(bytes);
-                if (kWidths[l] >= act_split_min_c_) L.actbuf[l] = (unsigned short*)alloc(bytes);
             }
             const size_t tiles0 = (size_t)ceil_div(h, 4) * ceil_div(w, 32);
             L.stats = (float*)alloc((size_t)per * tiles0 * 16 * 4);
@@ -865,17 +860,14 @@ void Engine::build_program() {
         o.stats_out = (cw.kind != CONV_UP || upf) && cw.kind != CONV_HEAD;
         program_.push_back(o);
     };
-    auto act = [&](int in0, int out, int l) { Op o; o.kind = Op::ACT; o.in0 = in0; o.out = out; o.lin = o.lout = l; program_.push_back(o); };
     // ResBlock: out = x + conv2(silu(gn2(conv1(silu(gn1(x)))))); the partials of x were written by x's producer
     auto resblock = [&](const RBW& rb, int x, int tmp, int out, int l, const std::string& name) {
-        const bool split = v2 && kWidths[l] >= act_split_min_c_;      // activation as its own pass (A/B switch, off by default)
-        const int ab_buf = buf_id(l, 5);
+        // GroupNorm+FiLM+SiLU is applied by the consuming conv while it stages its input (a separate activation pass lost every
+        // A/B from round 1 to round 3 and was removed in round 4)
         gn(rb.gn1);
-        if (split) act(x, ab_buf, l);
-        conv(rb.conv1, split ? ab_buf : x, BUF_NONE, BUF_NONE, tmp, l, l, !split, name + ".h");
+        conv(rb.conv1, x, BUF_NONE, BUF_NONE, tmp, l, l, true, name + ".h");
         gn(rb.gn2);
-        if (split) act(tmp, ab_buf, l);     // h is only ever read through GN2+SiLU (capture keeps raw h)
-        conv(rb.conv2, split ? ab_buf : tmp, BUF_NONE, x, out, l, l, !split, name);
+        conv(rb.conv2, tmp, BUF_NONE, x, out, l, l, true, name);
     };
     conv(net_.stem, BUF_NONE, BUF_NONE, BUF_NONE, buf_id(0, 0), 0, 0, false, "stem");
     int x = buf_id(0, 0);
@@ -914,7 +906,7 @@ Geo Engine::geo_of_lane(const Lane& L, int nimg, int h, int w, const uint8_t* d_
     for (int l = 0; l < 4; ++l) {
         for (int b = 0; b < 4; ++b) g.buf[l][b] = L.act[l][b];
         g.buf[l][4] = l < 3 ? L.skip[l] : nullptr;
-        g.buf[l][5] = L.actbuf[l];
+        g.buf[l][5] = nullptr;
     }
     g.img_in = d_in; g.img_out = d_out;
     return g;
@@ -974,7 +966,6 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     a.group_size = std::max(1, a.cout / 8);
     a.stamps = nullptr;
     a.prio_young = prio_young_;
-    a.w4_waves = (a.ab == nullptr) ? w4_waves_ : 8;
     if (stamps_dev_ && rb && cw.cout == stamps_cout_ && (cw.kind == CONV_RB2) == stamps_resid_ && (!stamps_taken_ || !stamps_tl_.empty() || std::getenv("IRE_STAMPS_RAW"))) {
         a.stamps = stamps_dev_;
         stamps_taken_ = true;
@@ -991,8 +982,8 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     if (cw.kind == CONV_FUSE) fam = FAM_CONV1;
     else if (cw.kind == CONV_STEM) fam = FAM_STEM;
     else if (cw.kind == CONV_HEAD) fam = FAM_HEAD;
-    // conv_w4: pre-activated input (ab == nullptr) or, from w4_fused_min_c_ up, activation fused into its staging (8-wave form)
-    const bool w4 = rb && rb_tile_h_ == kRbTileH && use_w4_ && cw.d_w4 != nullptr && (a.ab == nullptr || cw.cout >= w4_fused_min_c_);
+    // conv_w4: the C >= 128 ResBlock convs, activation fused into its staging
+    const bool w4 = rb && rb_tile_h_ == kRbTileH && use_w4_ && cw.d_w4 != nullptr && a.ab != nullptr && cw.cout >= 128;
     if (R.gn_pending) {
         // the deferred GroupNorm finalize of this conv's input: inside the kernel's prologue where it has one (gn_fold.hpp)
         const bool folds = a.ab != nullptr && (w4 || head_rb || (rb && rb_tile_h_ == kRbTileH));
@@ -1022,7 +1013,7 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
             // the GroupNorm partials of a tile in different fp32 orders: a result must not depend on the batch around it or on the strip
             // decomposition (tests: batch invariance, tiled == untiled).  Rule: a batch of 8 such images would not fill the CUs.
             const int tiles_img = ceil_div(g.H >> op.lout, kRbTileH) * ceil_div(g.w >> op.lout, 32);
-            if (w4_split_ && cw.d_w4h && a.ab != nullptr && cw.d_w8 == nullptr && a.w4_waves == 8 && tiles_img * a.nblocks * 8 < 256) {
+            if (w4_split_ && cw.d_w4h && a.ab != nullptr && cw.d_w8 == nullptr && tiles_img * a.nblocks * 8 < 256) {
                 a.w = cw.d_w4h; a.nblocks = cw.cout / 64; a.w4_nt = 64;
             }
         }
@@ -1102,15 +1093,6 @@ void Engine::exec_op(Run& R, const Op& op, const Geo& g) {
             // or this is a row strip (one finalize over the gathered array serves all strips)
             R.gn_pending = op.gn; R.gn_stats = R.stats; R.gn_parts = R.stat_parts;
             if (!gn_fold_ || g.halo) flush_gn(R, g);
-            break;
-        }
-        case Op::ACT: {
-            const int l = op.lin, Ht = g.h >> l, Wt = g.w >> l, C = kWidths[l];
-            if (g.halo) fail(IRE_ERR_INTERNAL, "internal: the separate activation pass is not available in strip mode");
-            if (R.gn_pending) flush_gn(R, g);
-            prof_begin(FAM_GN, R.stream, 0, 2.0 * g.nimg * Ht * Wt * C * 2);
-            gn_apply_silu_launch(g.buf[op.in0 >> 3][op.in0 & 7], R.ab, g.buf[op.out >> 3][op.out & 7], g.nimg, Ht * Wt, C, R.stream);
-            prof_end(R.stream);
             break;
         }
         case Op::CONV: exec_conv(R, op, g); break;

@@ -68,7 +68,6 @@ struct Lane {
     hipEvent_t done = nullptr;
     unsigned short* act[4][4] = {};
     unsigned short* skip[3] = {};
-    unsigned short* actbuf[4] = {};   // activated copy of a ResBlock conv input (levels with C >= act_split_min_c)
     float* stats = nullptr;
     float* stats2 = nullptr;          // second partials array: a conv that finalizes its input's GroupNorm itself (gn_fold.hpp) reads one and writes the other
     float2* ab = nullptr;
@@ -78,12 +77,12 @@ struct Lane {
 // batch (restore_device) or over the row strips of one image with a halo exchange after every op whose output feeds a
 // 3x3 convolution and a gather of the GroupNorm partials before every OP_GN (cfg 4: engine.cpp "strips") ----
 constexpr int BUF_NONE = -1;
-inline int buf_id(int level, int slot) { return level * 8 + slot; }   // slot 0..3 = act[level][slot], 4 = skip[level], 5 = actbuf[level]
+inline int buf_id(int level, int slot) { return level * 8 + slot; }   // slot 0..3 = act[level][slot], 4 = skip[level]
 struct Op {
-    enum Kind { GN, ACT, CONV } kind = CONV;
+    enum Kind { GN, CONV } kind = CONV;
     const GNW* gn = nullptr;          // GN: finalize the partials of the tensor produced last -> (A, B) per (image, channel)
     const ConvW* cw = nullptr;        // CONV
-    int in0 = BUF_NONE, in1 = BUF_NONE, resid = BUF_NONE, out = BUF_NONE;   // ACT: in0 -> out
+    int in0 = BUF_NONE, in1 = BUF_NONE, resid = BUF_NONE, out = BUF_NONE;
     int lin = 0, lout = 0;            // levels of in0 / out
     bool use_ab = false;              // CONV: GroupNorm+FiLM+SiLU applied while staging in0
     bool halo_out = false;            // the output is read by a 3x3 convolution: strips exchange its boundary rows
@@ -221,11 +220,9 @@ private:
     int num_lanes_ = 1;
     uint32_t flags_ = 0;
     int precision_ = IRE_PRECISION_BF16;
-    int w4_fused_min_c_ = 128;      // IRE_W4_FUSED_MINC: ResBlock convs with fused activation and cout >= this run on conv_w4's fused variant
-    int w4_waves_ = 8;            // IRE_W4_WAVES=4: the one-wave-per-SIMD form, pre-activated inputs only (fused activation needs the 8-wave form)
     int w4_split_ = 1;            // IRE_W4_SPLIT=0: never use the 64-cout items
     int use_pk_ = 1;              // C >= 128 ResBlock convs (128-cout items, fused activation) on conv_pk.hip's producer / consumer workgroups: 1 = the convs without a residual, 2 = all (IRE_PK=0: conv_w4.hip)
-    int use_w4_ = 1;              // C >= 128 ResBlock convs on conv_w4.hip (IRE_W4=0: conv_rb.hip; IRE_W4_WAVES=4|8)
+    int use_w4_ = 1;              // C >= 128 ResBlock convs on conv_w4.hip (IRE_W4=0: conv_rb.hip)
     int fp8_mx_ = 1;              // fp8: the block-scaled K = 64 MFMA (conv_f8.hip); IRE_FP8_MX=0: the same-rate 32x32x16 fp8 form in conv_w4.hip
     int down_rb_ = 1;             // stride-2 `down` convs on conv_down.hip's pipelined phase kernel (IRE_DOWN_RB=0: the v1 kernel)
     int head_rb_ = 1;             // the 32 -> 3 head conv on conv_rb.hip's pipelined kernel (IRE_HEAD_RB=0: the v1 kernel)
@@ -236,7 +233,6 @@ private:
     int up_subpixel_ = 1;         // `up` convs as sub-pixel convolutions on the low-res grid (IRE_UP_SUBPIX=0: nearest x2 + 3x3 on conv_rb.hip)
     int up_rb_min_c_ = 32;        // `up` convs with cout >= this run on conv_rb.hip (IRE_UP_RB_MINC), the rest on the v1 kernel
     int prio_young_ = 0;          // static s_setprio for waves 4-7 of conv_rb (A/B'd: it only swaps which half waits)
-    int act_split_min_c_ = 512;  // IRE_ACT_SPLIT_MINC: ResBlock convs with C >= this read a pre-activated tensor (gn_apply_silu pass); none by default (same-box A/B, r01: 128 -> 747, 256 -> 763 img/s; with conv_w4's fused variant from C = 128: 256 -> 796, 512 -> 799.5)
     int rb_tile_h_ = kRbTileH;  // 16: persistent pipelined conv_rb.hip; 8: conv_mfma.hip (IRE_CONV_V1=1)
     std::mutex mu_;
     hipStream_t main_stream_ = nullptr;

@@ -29,36 +29,6 @@ __global__ __launch_bounds__(512) void gn_finalize_kernel(ConvArgs a) {
     gn_fold(a, smem, blockIdx.x, blockIdx.x, 512);
 }
 
-// y = silu(x*A[n][c] + B[n][c]) as its own pass: used for the C >= 128 levels, where every input element
-// would otherwise be re-activated by each of the 2-4 n-block workgroups that read it (the SIMDs of the
-// conv kernel are instruction-issue bound, not HBM bound, there).  16 B per lane, in place or out of place.
-__global__ __launch_bounds__(256) void gn_apply_silu_kernel(const uint4* __restrict__ x, const float2* __restrict__ ab,
-                                                            uint4* __restrict__ out, int chunks_per_img, int c8n) {
-    const int img = blockIdx.y;
-    const float2* abi = ab + (size_t)img * c8n * 8;
-    const uint4* xi = x + (size_t)img * chunks_per_img;
-    uint4* oi = out + (size_t)img * chunks_per_img;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < chunks_per_img; i += gridDim.x * blockDim.x) {
-        const int c8 = i % c8n;
-        const float4* cf = reinterpret_cast<const float4*>(abi + c8 * 8);
-        const uint4 v = xi[i];
-        unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const float4 c = cf[d];                       // (A0, B0, A1, B1)
-            const float y0 = __builtin_fmaf(__builtin_bit_cast(float, w[d] << 16), c.x, c.y);
-            const float y1 = __builtin_fmaf(__builtin_bit_cast(float, w[d] & 0xffff0000u), c.z, c.w);
-            const float s0 = y0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * y0));
-            const float s1 = y1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * y1));
-            typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-            typedef float f2 __attribute__((ext_vector_type(2)));
-            f2 f = {s0, s1};
-            w[d] = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf2));
-        }
-        oi[i] = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-}
-
 __global__ void film_kernel(const float* __restrict__ cond, const float* __restrict__ w,
                             const float* __restrict__ b, int nout, float* __restrict__ film) {
     const int img = blockIdx.y;
@@ -79,15 +49,6 @@ void gn_finalize_launch(const float* d_stats, int nimg, int ntiles, int C, int h
     a.cin0 = C; a.gn_stats = d_stats; a.gn_parts = ntiles; a.gn_hw = hw; a.gn_gamma = d_gamma; a.gn_beta = d_beta;
     a.gn_film = d_film; a.gn_film_stride = film_stride; a.gn_film_off = film_off; a.ab_w = d_ab;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(nimg), dim3(512), 0, stream, a);
-    IRE_HIP(hipGetLastError());
-}
-
-void gn_apply_silu_launch(const unsigned short* d_x, const float2* d_ab, unsigned short* d_out, int nimg, int hw, int C,
-                          hipStream_t stream) {
-    const int chunks = hw * (C / 8);
-    const int bx = std::min(ceil_div(chunks, 256 * 4), 2048 / std::max(1, nimg) + 1);
-    hipLaunchKernelGGL(gn_apply_silu_kernel, dim3(bx, nimg), dim3(256), 0, stream, reinterpret_cast<const uint4*>(d_x), d_ab,
-                       reinterpret_cast<uint4*>(d_out), chunks, C / 8);
     IRE_HIP(hipGetLastError());
 }
 

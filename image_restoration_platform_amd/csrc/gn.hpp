@@ -10,10 +10,6 @@ void gn_finalize_launch(const float* d_stats, int nimg, int ntiles, int C, int h
                         const float* d_beta, const float* d_film, int film_stride, int film_off,
                         float2* d_ab, hipStream_t stream);
 
-// out = bf16(silu(x*A + B)) per (image, channel); x/out: [nimg][hw][C] bf16; may be in place.
-void gn_apply_silu_launch(const unsigned short* d_x, const float2* d_ab, unsigned short* d_out, int nimg, int hw, int C,
-                          hipStream_t stream);
-
 // film[nimg][nout] = W[nout][7] * cond[nimg][8 (7 used)] + b
 void film_launch(const float* d_cond, int nimg, const float* d_w, const float* d_b, int nout, float* d_film,
                  hipStream_t stream);

@@ -30,7 +30,7 @@ size_t StripSession::stats_floats(int H, int W) { return (size_t)ceil_div(H, 4) 
 StripSession::StripSession(Engine& eng, int H, int W, int nstrips_total, int first_strip, int nlocal, float* d_stats_external)
     : E(eng), H_(H), W_(W), total_(nstrips_total), first_(first_strip), nlocal_(nlocal) {
     if (!E.net_.loaded) fail(IRE_ERR_UNAVAILABLE, "service unavailable: RestoreNet weights are not loaded");
-    if (E.act_split_min_c_ < 512 || E.rb_tile_h_ != kRbTileH)
+    if (E.rb_tile_h_ != kRbTileH)
         fail(IRE_ERR_INVALID_INPUT, "invalid configuration for strip mode: the A/B schedule switches must be at their defaults");
     if (H <= 0 || W <= 0 || H > 8192 || W > 8192 || W % 8) fail(IRE_ERR_INVALID_INPUT, "invalid image size for tiled restore");
     if (nstrips_total < 1 || nstrips_total > 64 || H % nstrips_total) fail(IRE_ERR_INVALID_INPUT, "invalid strip count: it must divide the image height");

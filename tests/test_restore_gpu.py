@@ -91,12 +91,12 @@ def test_seeded_random_shapes_vs_fp32_oracle(engine, weights0):
         _assert_close(engine.restore(imgs, scores=sc), onet.restore(imgs, sc, weights0))
 
 
-@pytest.mark.parametrize("env", [{"IRE_W4": "0"}, {"IRE_W4_WAVES": "4", "IRE_ACT_SPLIT_MINC": "128"}, {"IRE_W4_WAVES": "4"}, {"IRE_CONV_V1": "1"}, {"IRE_UP_RB_MINC": "64"},
-                                 {"IRE_ACT_SPLIT_MINC": "64"}, {"IRE_ACT_SPLIT_MINC": "128"}, {"IRE_UP_SUBPIX": "0"}, {"IRE_UP_FUSE": "0"}, {"IRE_GN_FOLD": "0"}, {"IRE_PC": "0"}, {"IRE_PC": "1"}, {"IRE_PC": "7"}, {"IRE_PC": "3"}, {"IRE_PC": "0", "IRE_GN_FOLD": "0"}, {"IRE_DOWN_RB": "0", "IRE_HEAD_RB": "0"}, {"IRE_STEM_RB": "0"},
-                                 {"IRE_W4_FUSED_MINC": "100000", "IRE_ACT_SPLIT_MINC": "256"}, {"IRE_W4_FUSED_MINC": "100000"}, {"IRE_W4_SPLIT": "0"}, {"IRE_PK": "0"}, {"IRE_PK": "2"}])
+@pytest.mark.parametrize("env", [{"IRE_W4": "0"}, {"IRE_CONV_V1": "1"}, {"IRE_UP_RB_MINC": "64"},
+                                 {"IRE_UP_SUBPIX": "0"}, {"IRE_UP_FUSE": "0"}, {"IRE_GN_FOLD": "0"}, {"IRE_PC": "0"}, {"IRE_PC": "1"}, {"IRE_PC": "7"}, {"IRE_PC": "3"}, {"IRE_PC": "0", "IRE_GN_FOLD": "0"}, {"IRE_DOWN_RB": "0", "IRE_HEAD_RB": "0"}, {"IRE_STEM_RB": "0"},
+                                 {"IRE_W4_SPLIT": "0"}, {"IRE_PK": "0"}, {"IRE_PK": "2"}])
 def test_alternate_kernel_schedules_agree(engine, weights0, env, monkeypatch):
-    """Every A/B switch of the engine (conv_rb instead of conv_w4 at C >= 128, the 4-wave conv_w4, the v1 conv schedule, the
-    v1 `up` kernel, the separate activation pass from C = 64, nearest x2 + 3x3 instead of the sub-pixel `up` convolution) computes the same network: each meets the oracle bound, and
+    """Every A/B switch of the engine (conv_rb instead of conv_w4 at C >= 128, the v1 conv schedule, the
+    v1 `up` kernel, nearest x2 + 3x3 instead of the sub-pixel `up` convolution) computes the same network: each meets the oracle bound, and
     differs from the default schedule only through fp32 summation order of the GroupNorm partials (bf16 roundings of
     intermediate activations flip: <= 2 LSB, and only a minority of output samples move at all)."""
     from image_restoration_platform_amd.engine import Engine

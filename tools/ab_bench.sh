@@ -2,7 +2,7 @@
 # (boxes of the pool differ by several %, two runs on one box by < 1 %)
 set -e
 cd $GRAFT_REPO_ROOT
-LIST="${AB_LIST:-default IRE_NOP=1;w4off IRE_W4=0;w4x4 IRE_W4_WAVES=4;up64 IRE_UP_RB_MINC=64;slot IRE_SLOT_STATS=1;lanes2 IRE_STREAMS=2}"
+LIST="${AB_LIST:-default IRE_NOP=1;w4off IRE_W4=0;up64 IRE_UP_RB_MINC=64;slot IRE_SLOT_STATS=1;lanes2 IRE_STREAMS=2}"
 for rep in 1 2; do
   echo "$LIST" | tr ';' '\n' | while read -r name envs; do
     [ -z "$name" ] && continue
