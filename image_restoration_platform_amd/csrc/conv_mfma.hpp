@@ -93,6 +93,7 @@ struct ConvArgs {
     int fp8;                     // conv_w4: OCP e4m3 operands (a.w = fp8 slabs, a.bias = bias / oscale)
     const float* oscale;         // fp8: [cout] accumulator -> output scale (weight scale of the channel / activation scale)
     int w4_nt;                   // conv_w4 cout block: 128 (default, 0) or 64 (launches whose 128-cout items would leave CUs idle; a.w = the 64-cout slabs)
+    const void* zeros;           // conv_upq.hip: >= 16 bytes of zeros (what a DMA lane outside the image fetches)
     unsigned long long* stamps;  // diagnostic builds only (IRE_RB_ABLATE, DBG bit 16): s_memtime stamps, else null
 };
 
@@ -132,6 +133,9 @@ bool conv_pk_fits(int C, int tiles_per_img, int nimg);
 // CONV_UP as a sub-pixel convolution on the low-resolution grid (conv_up.hip): 4 output parities x 2x2 pre-summed taps.
 // a.Hin/Win = low-res source, a.Hout/Wout = 2x; a.nkc = Cin/32 (even), a.nblocks = cout/32, tiles of 16x32 LOW-res pixels.
 void conv_up_subpixel_launch(const ConvArgs& a, hipStream_t stream);
+// The fused `up` + `fuse` with cout = 128 as parity-major items (conv_upq.hip): a.w = d_wuq, a.w1 = d_wsq, a.nkc = Cin / 32, a.nblocks = 4
+// (parities), 16 x 32 LOW-res tiles, a.zeros, partials [img][tile * 4 + parity][8][2] (four rows per low-res tile).
+void conv_upq_launch(const ConvArgs& a, hipStream_t stream);
 // CONV_UP through the same pipelined kernel (Hin/Win = low-res source, Hout/Wout = 2x; a.stats = nullptr).
 void conv_up_launch(const ConvArgs& a, hipStream_t stream);
 

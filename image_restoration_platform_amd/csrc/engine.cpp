@@ -94,6 +94,7 @@ Engine::Engine(const ire_config& cfg) {
     if (const char* v = std::getenv("IRE_GN_FOLD")) gn_fold_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_PC")) pc_split_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_PK")) use_pk_ = std::atoi(v);
+    if (const char* v = std::getenv("IRE_UPQ")) use_upq_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_HEAD_RB")) head_rb_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_DOWN_RB")) down_rb_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_STEM_RB")) stem_rb_ = std::atoi(v);
@@ -188,7 +189,7 @@ Engine::~Engine() {
     for (void* p : net_.allocs) (void)hipFree(p);
     for (void* p : table_allocs_) (void)hipFree(p);
     for (void* p : {(void*)d_in_, (void*)d_out_, (void*)d_jpeg_, (void*)d_sums_, (void*)d_scores_, (void*)d_label_,
-                    (void*)d_cond_, (void*)d_film_, (void*)d_fL_, (void*)d_fQ_, (void*)d_fsad_, (void*)d_fmisc_, (void*)d_fwlut_, (void*)d_pp_tab_, (void*)d_pp_mid_, (void*)d_pp_in_, (void*)d_pp_out_, (void*)d_enc_scratch_, (void*)d_enc_io_})
+                    (void*)d_cond_, (void*)d_film_, d_zero_, (void*)d_fL_, (void*)d_fQ_, (void*)d_fsad_, (void*)d_fmisc_, (void*)d_fwlut_, (void*)d_pp_tab_, (void*)d_pp_mid_, (void*)d_pp_in_, (void*)d_pp_out_, (void*)d_enc_scratch_, (void*)d_enc_io_})
         if (p) (void)hipFree(p);
     for (auto& L : lanes_) {
         if (L.stream) (void)hipStreamDestroy(L.stream);
@@ -483,6 +484,36 @@ void Engine::make_up_fused(ConvW& up, const std::string& sl) {
                     for (int e = 0; e < 8; ++e)
                         arrs[((((size_t)nb * nks + ks) * 2 + hh) * 32 + n) * 8 + e] =
                             f32_to_bf16(Wf[(size_t)(nb * 32 + perm(n)) * 2 * C + C + ks * 16 + hh * 8 + e]);
+    if (C == 128) {
+        // conv_upq.hip: the same composed, pre-summed weights (the same single rounding) as 128-cout slabs per output parity, and the
+        // skip half as four 32-channel stages
+        std::vector<unsigned short> arrq((size_t)4 * nku * 16 * 128 * 8, 0);
+        for (int par = 0; par < 4; ++par)
+            for (int kc = 0; kc < nku; ++kc)
+                for (int kk = 0; kk < 16; ++kk) {
+                    const int pa = par >> 1, pb = par & 1, tap4 = kk >> 2, c8 = kk & 3, dy = tap4 >> 1, dx = tap4 & 1;
+                    for (int n = 0; n < 128; ++n)
+                        for (int e = 0; e < 8; ++e) {
+                            const int co = perm(n), ci = kc * 32 + c8 * 8 + e;
+                            double sum = 0.0;
+                            for (int ky = lo_of(pa, dy); ky <= hi_of(pa, dy); ++ky)
+                                for (int kx = lo_of(pb, dx); kx <= hi_of(pb, dx); ++kx) sum += Wc[((size_t)co * cin + ci) * 9 + ky * 3 + kx];
+                            arrq[((((size_t)par * nku + kc) * 16 + kk) * 128 + n) * 8 + e] = f32_to_bf16((float)sum);
+                        }
+                }
+        std::vector<unsigned short> arrsq((size_t)(C / 32) * 4 * 128 * 8, 0);
+        for (int ks = 0; ks < C / 32; ++ks)
+            for (int c8 = 0; c8 < 4; ++c8)
+                for (int n = 0; n < 128; ++n)
+                    for (int e = 0; e < 8; ++e)
+                        arrsq[(((size_t)ks * 4 + c8) * 128 + n) * 8 + e] = f32_to_bf16(Wf[(size_t)perm(n) * 2 * C + C + ks * 32 + c8 * 8 + e]);
+        if (!d_zero_) { d_zero_ = dalloc(256); IRE_HIP(hipMemset(d_zero_, 0, 256)); }
+        up.d_wuq = (unsigned short*)dalloc(arrq.size() * 2);
+        up.d_wsq = (unsigned short*)dalloc(arrsq.size() * 2);
+        net_.allocs.push_back(up.d_wuq); net_.allocs.push_back(up.d_wsq);
+        IRE_HIP(hipMemcpy(up.d_wuq, arrq.data(), arrq.size() * 2, hipMemcpyHostToDevice));
+        IRE_HIP(hipMemcpy(up.d_wsq, arrsq.data(), arrsq.size() * 2, hipMemcpyHostToDevice));
+    }
     up.d_wuf = (unsigned short*)dalloc(arru.size() * 2);
     up.d_wsk = (unsigned short*)dalloc(arrs.size() * 2);
     up.d_bias_uf = (float*)dalloc(C * 4);
@@ -942,6 +973,10 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     const bool up_rb = (cw.kind == CONV_UP) && rb_tile_h_ == kRbTileH && cw.cout >= up_rb_min_c_;
     const bool up_sub = up_rb && up_subpixel_ && cw.d_wu != nullptr;       // sub-pixel form: tiles and halo rows on the LOW-res grid
     const bool up_fused = up_sub && op.in1 != BUF_NONE;                     // composed with the 1x1 `fuse` (build_program)
+    // cout = 128: parity-major items with all 128 couts (conv_upq.hip); four partial rows per low-res tile.  (fp8 engines and every
+    // other level: conv_up.hip.)  A function of the layer only: batch / strip invariance holds.
+    const bool up_q = up_fused && use_upq_ && cw.d_wuq != nullptr && cw.cout == 128 && cw.cin % 32 == 0;
+    const int parts_mul = up_q ? 4 : 1;
     const bool head_rb = cw.kind == CONV_HEAD && rb_tile_h_ == kRbTileH && head_rb_ && cw.d_wp != nullptr;    // the head on the pipelined kernel
     const bool down_rb = cw.kind == CONV_DOWN && rb_tile_h_ == kRbTileH && down_rb_ && cw.d_wd != nullptr;    // stride-2 convs by pixel phase
     const bool stem_rb = cw.kind == CONV_STEM && rb_tile_h_ == kRbTileH && stem_rb_ && cw.d_wstem != nullptr && op.stats_out;  // the stem on its own kernel
@@ -960,7 +995,7 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
         const int sl = up_fused ? op.lin : op.lout;
         const int ty0 = (g.y0 >> sl) / th;
         float* dst = R.stats_alt ? R.stats_alt : R.stats;         // ping-pong: this conv may still be reading R.stats in its folded finalize
-        a.stats = dst + (size_t)ty0 * a.tiles_x * 16;
+        a.stats = dst + (size_t)ty0 * a.tiles_x * 16 * parts_mul;
     }
     a.nimg = g.nimg; a.nblocks = cw.nblocks;
     a.group_size = std::max(1, a.cout / 8);
@@ -1033,6 +1068,12 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     } else if (head_rb) { a.w = cw.d_wp; if (pc_split_ & 1) { conv_pc_launch(false, true, a, R.stream); kname = "conv_pc"; } else { conv_head_launch(a, R.stream); kname = "conv_rb"; } }
     else if (down_rb) { a.w = cw.d_wd; a.nkc = cw.cin / 32; a.nblocks = cw.cout / 64; conv_down_launch(a, R.stream); kname = "conv_down"; }
     else if (stem_rb) { a.w = cw.d_wstem; conv_stem_launch(a, R.stream); kname = "conv_stem"; }
+    else if (up_q) {
+        a.w = cw.d_wuq; a.w1 = cw.d_wsq; a.bias = cw.d_bias_uf; a.nkc = cw.cin / 32; a.nblocks = 4;
+        a.in1 = in_ptr(op.in1) + (size_t)g.halo * Wout * cw.cout;
+        a.cin1 = cw.cout; a.zeros = d_zero_;
+        conv_upq_launch(a, R.stream); kname = "conv_upq";
+    }
     else if (up_fused) {
         a.w = cw.d_wuf; a.w1 = cw.d_wsk; a.bias = cw.d_bias_uf; a.nkc = cw.cin / 32; a.nblocks = cw.cout / 32;
         a.in1 = in_ptr(op.in1) + (size_t)g.halo * Wout * cw.cout;      // the skip tensor is read at output pixels only: first real row
@@ -1071,7 +1112,7 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     prof_end(R.stream);
     if (op.stats_out) {
         const int sl = up_fused ? op.lin : op.lout;
-        R.stat_parts = a.tiles_x * ceil_div(g.H >> sl, th);
+        R.stat_parts = a.tiles_x * ceil_div(g.H >> sl, th) * parts_mul;
         if (R.stats_alt) std::swap(R.stats, R.stats_alt);          // R.stats = the partials produced last
     }
     if (capture_ && !op.name.empty() && a.out && g.halo == 0) capture(op.name.c_str(), a.out, (size_t)g.nimg * Hout * Wout * cw.cout, R.stream);

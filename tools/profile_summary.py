@@ -29,7 +29,7 @@ def stats(src, dst, title, footer=""):
 def is_conv3x3(name):
     if "conv_rb_kernel" in name or "conv_pc_kernel" in name:   # the HEAD instantiation (last template argument true) is its own family
         return not name.rstrip().endswith(", true>(ire::ConvArgs)")
-    if "conv_w4_kernel" in name or "conv_up_kernel" in name or "conv_down_kernel" in name or "conv_f8_kernel" in name or "conv_pk_kernel" in name:
+    if "conv_w4_kernel" in name or "conv_up_kernel" in name or "conv_down_kernel" in name or "conv_f8_kernel" in name or "conv_pk_kernel" in name or "conv_upq_kernel" in name:
         return True
     if "conv_mfma_kernel<4, 9," in name and not name.rstrip().endswith("true>(ire::ConvArgs)"):   # last arg = HEAD: its own family
         return True
@@ -71,6 +71,8 @@ def group_of(name, k):
         return "down%d" % (k % 3)
     if "conv_up_kernel<" in n:
         return {"2": "up0", "4": "up1", "8": "up2"}.get(n[n.find("<") + 1:n.find(">")])
+    if "conv_upq_kernel" in n:
+        return "up2"
     if "conv_stem_kernel" in n:
         return "stem"
     return None
@@ -90,7 +92,7 @@ def traffic(fetch_csv, write_csv, dst, steps):
     out = {
         "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile",
         "unit_note": "counters are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); WRITE_SIZE as is",
-        "family": "conv3x3 (conv_pc_kernel / conv_rb_kernel without their HEAD instantiation, conv_w4_kernel, conv_f8_kernel, conv_up_kernel, conv_down_kernel; the v1 stride-2 conv_mfma_kernel instantiation where a switch selects it)",
+        "family": "conv3x3 (conv_pc_kernel / conv_rb_kernel without their HEAD instantiation, conv_w4_kernel, conv_f8_kernel, conv_up_kernel, conv_upq_kernel, conv_down_kernel; the v1 stride-2 conv_mfma_kernel instantiation where a switch selects it)",
         "per_kernel": {},
     }
     tot_f = tot_w = 0.0
