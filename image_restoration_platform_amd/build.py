@@ -26,7 +26,7 @@ SOURCES = [
     ("conv_up.hip", (["-DIRE_UP_ABL=" + os.environ["IRE_UP_ABL"]] if os.environ.get("IRE_UP_ABL") else []) +
      (["-DIRE_UP_D=" + os.environ["IRE_UP_D"]] if os.environ.get("IRE_UP_D") else []) +
      (["-DIRE_UP_TEPI=" + os.environ["IRE_UP_TEPI"]] if os.environ.get("IRE_UP_TEPI") else [])),
-    ("conv_upq.hip", (["-DUQ_ABL=" + os.environ["UQ_ABL"]] if os.environ.get("UQ_ABL") else [])),
+    ("conv_upq.hip", os.environ.get("UQ_DEFS", "").split()),
     ("conv_down.hip", (["-DDN_LD_NT=" + os.environ["DN_LD_NT"]] if os.environ.get("DN_LD_NT") else [])),
     ("conv_stem.hip", []),
     ("conv_f8.hip", []),

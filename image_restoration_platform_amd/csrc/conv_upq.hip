@@ -15,8 +15,9 @@
 //   * nothing is activated on the way in (the `up` input carries no GroupNorm), so ALL staging is LDS-DMA, issued by the eight
 //     computing waves one stage ahead into the other buffer pair (tile 36 KB + slab 32 KB, two pairs): no staging registers, no
 //     vector instructions besides the addresses; zero padding = lanes outside the image fetch from a page of zeros;
-//   * epilogue: conv_pk.hip's line-coalesced form (a wave transposes 16 pixels x 128 couts through a 4-KB patch and stores whole
-//     256-B pixel runs), the patches being the wave's own DMA region of the tile buffer the item's last stage has finished with.
+//   * epilogue: conv_pk.hip's line-coalesced form (a wave transposes 8 pixels x 128 couts at a time through a 2-KB patch of its own and
+//     stores whole 256-B pixel runs); the DMA pieces of the stage after next are issued IN FRONT of the stores and the next barrier
+//     waits for "all but the 16 youngest" operations: the 128-KB-per-CU store burst drains behind the next stage's MFMAs.
 // One barrier per stage (12 per item).  GroupNorm partials: one (sum, sumsq) per group per ITEM, i.e. FOUR partial rows per low-res
 // tile (index tile * 4 + parity): the engine tells the finalize so (exec_conv: stat_parts).
 // Weights: a.w = [parity][kc32][tap4][c8][128 rows, permuted like conv_w4's][8] bf16 (engine.cpp::make_up_fused d_wuq),
@@ -37,7 +38,7 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 #ifndef UQ_ABL
-#define UQ_ABL 0      // timing ablations (results wrong by design): 1 no skip stages, 2 no epilogue, 4 no MFMA loop
+#define UQ_ABL 0      // timing ablations (results wrong by design): 1 no skip stages, 2 no epilogue, 4 no MFMA loop, 8 no tile DMA, 16 no slab DMA, 64 the k-loop twice
 #endif
 
 constexpr int UQ_THREADS = 512;
@@ -50,9 +51,10 @@ constexpr int UQ_W_BASE = 2 * UQ_TILE_BYTES;                    // LDS: tile[2] 
 constexpr int UQ_RED_BASE = UQ_W_BASE + 2 * UQ_SLAB_BYTES;
 constexpr int UQ_RED_BYTES = 2 * 8 * 16 * 2 * 4;                // [item parity][8 waves][16 chunks of 8 couts][sum, sumsq]
 constexpr int UQ_BIAS_BASE = UQ_RED_BASE + UQ_RED_BYTES;
-constexpr int UQ_LDS = UQ_BIAS_BASE + UQ_NT * 4;
-constexpr int UQ_PATCH_BYTES = 16 * UQ_NT * 2;                  // 4 096: a wave's pieces 4w .. 4w + 3 of the tile buffer
-static_assert(UQ_LDS <= 160 * 1024 && 8 * UQ_PATCH_BYTES <= UQ_TILE_BYTES, "LDS");
+constexpr int UQ_PATCH_BASE = UQ_BIAS_BASE + UQ_NT * 4;
+constexpr int UQ_PATCH_BYTES = 8 * UQ_NT * 2;                   // 2 048: a wave's transpose patch, 8 pixels x 128 couts (LDS of its own: see the epilogue)
+constexpr int UQ_LDS = UQ_PATCH_BASE + 8 * UQ_PATCH_BYTES;
+static_assert(UQ_LDS <= 160 * 1024, "LDS");
 
 __device__ __forceinline__ unsigned uq_pack(float a, float b) {
     f32x2_t f = {a, b};
@@ -73,9 +75,13 @@ __device__ __forceinline__ float uq_swap32_add(float v) {
     asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
     return x + y;
 }
-// the stage barrier: this wave's DMA pieces have landed (vmcnt: the item's output stores with them -- they are a stage old), its
-// LDS reads are done; behind the barrier everybody's are
-__device__ __forceinline__ void uq_stage_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// the stage barrier: this wave's DMA pieces of the next stage have landed, its LDS reads are done; behind the barrier everybody's are.
+// KEEP = 16: the stage that follows an epilogue -- its successor's pieces were issued IN FRONT of the epilogue's 16 output stores
+// (vector-memory operations retire in issue order: "all but the 16 youngest" = exactly those pieces), so the stores drain in the
+// background instead of in front of a barrier (all 256 workgroups store 128 KB at the same moment: 30 us per launch when waited for).
+template <int KEEP> __device__ __forceinline__ void uq_stage_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(KEEP) : "memory");
+}
 
 __global__ __launch_bounds__(UQ_THREADS) void conv_upq_kernel(ConvArgs a) {
     constexpr int NT = UQ_NT, NTL = UQ_NTL, C = UQ_NT;
@@ -94,11 +100,9 @@ __global__ __launch_bounds__(UQ_THREADS) void conv_upq_kernel(ConvArgs a) {
     const int n_items = cursor.my_items, S = cursor.S;
     if (S == 0) return;
 
-    // ---- DMA addressing.  Wave w stages tile pieces 4w .. 4w + 3 (its own patch region: it may restage them as soon as ITS epilogue is
-    // done) and, w < 4, piece 32 + w.  Chunk slot s = piece * 64 + lane holds pixel p = s >> 2 of the 17 x 33 window (pitch 33), 8-channel
-    // chunk c8 = (s & 3) ^ ((p >> 2) & 3) (conv_up.hip's swizzle: conflict-free fragment reads).  A lane's slots sit at the same
-    // window position in every stage of an item: byte offsets within the image once per item (main: low-res input pixel, skip: the
-    // parity's output pixel), ~0u = outside (zero padding / dummy slot): that lane fetches from the page of zeros.
+    // ---- DMA addressing.  Wave w stages tile pieces 4w .. 4w + 3 and, w < 4, piece 32 + w.  Chunk slot s = piece * 64 + lane holds
+    // pixel p = s >> 2 of the 17 x 33 window (pitch 33), 8-channel chunk c8 = (s & 3) ^ ((p >> 2) & 3) (conv_up.hip's swizzle: conflict-free
+    // fragment reads).
     // A lane's slots sit at the same window position for the whole kernel: (py, px, c8) of its five pieces, packed once.
     unsigned slotc[5];
 #pragma unroll
@@ -111,48 +115,60 @@ __global__ __launch_bounds__(UQ_THREADS) void conv_upq_kernel(ConvArgs a) {
         slotc[d] = (unsigned)py | ((unsigned)px << 8) | ((unsigned)c8 << 16);
     }
     const char* const zeros = reinterpret_cast<const char*>(a.zeros);
-    // stage `st` -> buffer pair b (its readers are behind the last barrier)
-    auto dma_stage = [&](const PersistStage& st, int b) __attribute__((always_inline)) {
+    // The pieces of stage `st` for buffer pair b (its readers are behind the last barrier): sources and LDS destinations only -- the
+    // caller issues them (in the prologue at once; in a stage BETWEEN the MFMA pairs of the k-loop: a DMA instruction holds the wave's
+    // issue for 100+ cycles, and nine of them in front of the k-loop left the matrix pipe idle for a third of the stage).
+    // Order: tile pieces 4w .. 4w + 3, the wave's slab pieces (four, or one in a skip stage), tile piece 32 + w (waves 0..3).
+    struct Plan { const void* src[10]; unsigned dst[10]; int n; };
+    // a lane's byte offsets within the image, once per ITEM (main: low-res input pixel, skip: the parity's output pixel, both at
+    // channel 8 c8 of stage 0); ~0u = outside the image / a dummy slot: that lane fetches from the page of zeros.  A stage's plan
+    // is then base(image, stage) + offset: ~30 vector instructions in front of the k-loop instead of ~120.
+    unsigned moff[5], soff[5];
+    auto item_offsets = [&](const PersistItem& it) __attribute__((always_inline)) {
+        const int pa = it.nb >> 1, pb = it.nb & 1;
+        const int Y0 = it.ty * UQ_TH, X0 = it.tx * UQ_TW;
+        const int ybase = Y0 - 1 + pa - a.iy_lo, xbase = X0 - 1 + pb;
+#pragma unroll
+        for (int d = 0; d < 5; ++d) {
+            const int py = slotc[d] & 0xff, px = (slotc[d] >> 8) & 0xff, c8 = slotc[d] >> 16;
+            const int ry = ybase + py, ix = xbase + px;               // ry: row relative to the first readable one
+            const bool okm = py < UQ_IH && (unsigned)ry < (unsigned)a.iy_span && (unsigned)ix < (unsigned)a.Win;
+            moff[d] = okm ? (unsigned)((ry + a.iy_lo + a.in_row_off) * a.Win + ix) * (unsigned)(2 * Cin) + (unsigned)(c8 * 16) : ~0u;
+            const int ly = Y0 + py, lx = X0 + px;
+            const bool oks = py < UQ_TH && px < UQ_TW && ly < a.Hin && lx < a.Win;
+            soff[d] = oks ? (unsigned)((2 * ly + pa) * a.Wout + 2 * lx + pb) * (unsigned)(2 * C) + (unsigned)(c8 * 16) : ~0u;
+        }
+    };
+    auto plan_stage = [&](const PersistStage& st, int b, Plan& P) __attribute__((always_inline)) {
         const unsigned tdst = smem_lds + b * UQ_TILE_BYTES, sdst = smem_lds + UQ_W_BASE + b * UQ_SLAB_BYTES;
         const bool skip = st.kc >= NKC;
-        const int pa = st.it.nb >> 1, pb = st.it.nb & 1;
-        const int Y0 = st.it.ty * UQ_TH, X0 = st.it.tx * UQ_TW;
-        if (!skip) {
-            // low-res input pixel (Y0 - 1 + pa + py, X0 - 1 + pb + px), channels 32 kc + 8 c8 ..
-            const char* base = reinterpret_cast<const char*>(a.in0) + (size_t)st.it.img * a.in_rows * a.Win * (2 * Cin) + st.kc * 64;
-            const int ybase = Y0 - 1 + pa - a.iy_lo, xbase = X0 - 1 + pb;
+        const char* tsrc[5];
+        const char* base = skip ? reinterpret_cast<const char*>(a.in1) + (size_t)st.it.img * a.Hout * a.Wout * (2 * C) + (st.kc - NKC) * 64
+                                : reinterpret_cast<const char*>(a.in0) + (size_t)st.it.img * a.in_rows * a.Win * (2 * Cin) + st.kc * 64;
 #pragma unroll
-            for (int d = 0; d < 5; ++d) {
-                if (d == 4 && wv >= 4) break;
-                const int piece = d < 4 ? 4 * wv + d : 32 + wv;
-                const int py = slotc[d] & 0xff, px = (slotc[d] >> 8) & 0xff, c8 = slotc[d] >> 16;
-                const int ry = ybase + py, ix = xbase + px;           // ry: row relative to the first readable one
-                const bool ok = py < UQ_IH && (unsigned)ry < (unsigned)a.iy_span && (unsigned)ix < (unsigned)a.Win;
-                const unsigned off = (unsigned)((ry + a.iy_lo + a.in_row_off) * a.Win + ix) * (unsigned)(2 * Cin) + (unsigned)(c8 * 16);
-                uq_glds16(ok ? base + off : zeros, tdst + piece * 1024);
-            }
+        for (int d = 0; d < 5; ++d) {
+            const unsigned off = skip ? soff[d] : moff[d];
+            tsrc[d] = off != ~0u ? base + off : zeros;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { P.src[d] = tsrc[d]; P.dst[d] = tdst + (4 * wv + d) * 1024; }
+        int n = 4;
+        if (!skip) {
             const unsigned char* ws = reinterpret_cast<const unsigned char*>(a.w) + ((size_t)st.it.nb * NKC + st.kc) * UQ_SLAB_BYTES;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const int piece = wv + 8 * d;
-                uq_glds16(ws + (size_t)(piece * 64 + lane) * 16, sdst + piece * 1024);
-            }
+            for (int d = 0; d < 4; ++d) { const int piece = wv + 8 * d; P.src[4 + d] = ws + (size_t)(piece * 64 + lane) * 16; P.dst[4 + d] = sdst + piece * 1024; }
+            P.src[8] = tsrc[4]; P.dst[8] = tdst + (32 + (wv & 3)) * 1024;
+            P.src[9] = tsrc[4]; P.dst[9] = P.dst[8];
+            n = wv < 4 ? 9 : 8;
         } else {
-            // the parity's output pixel (2 (Y0 + py) + pa, 2 (X0 + px) + pb) of the skip tensor, channels 32 ks + 8 c8 ..
-            const char* base = reinterpret_cast<const char*>(a.in1) + (size_t)st.it.img * a.Hout * a.Wout * (2 * C) + (st.kc - NKC) * 64;
-#pragma unroll
-            for (int d = 0; d < 5; ++d) {
-                if (d == 4 && wv >= 4) break;
-                const int piece = d < 4 ? 4 * wv + d : 32 + wv;
-                const int py = slotc[d] & 0xff, px = (slotc[d] >> 8) & 0xff, c8 = slotc[d] >> 16;
-                const int ly = Y0 + py, lx = X0 + px;
-                const bool ok = py < UQ_TH && px < UQ_TW && ly < a.Hin && lx < a.Win;
-                const unsigned off = (unsigned)((2 * ly + pa) * a.Wout + 2 * lx + pb) * (unsigned)(2 * C) + (unsigned)(c8 * 16);
-                uq_glds16(ok ? base + off : zeros, tdst + piece * 1024);
-            }
             const unsigned char* ws = reinterpret_cast<const unsigned char*>(a.w1) + (size_t)(st.kc - NKC) * UQ_SKSLAB_BYTES;
-            uq_glds16(ws + (size_t)(wv * 64 + lane) * 16, sdst + wv * 1024);
+            P.src[4] = ws + (size_t)(wv * 64 + lane) * 16; P.dst[4] = sdst + wv * 1024;
+            P.src[5] = tsrc[4]; P.dst[5] = tdst + (32 + (wv & 3)) * 1024;
+#pragma unroll
+            for (int d = 6; d < 10; ++d) { P.src[d] = tsrc[4]; P.dst[d] = P.dst[5]; }
+            n = wv < 4 ? 6 : 5;
         }
+        P.n = n;
     };
 
     // ---- fragment addressing.  Pixel fragment (row m, tap (dy, dx), k-step k): window pixel p = (2w + m + dy) 33 + r + dx, chunk
@@ -192,10 +208,17 @@ __global__ __launch_bounds__(UQ_THREADS) void conv_upq_kernel(ConvArgs a) {
     PersistStage cs = cursor.cur;
     PersistStage cn = cursor.next();
     // ---- prologue: stage 0 into pair 0
-    dma_stage(cs, 0);
+    {
+        Plan P;
+        item_offsets(cs.it);
+        plan_stage(cs, 0, P);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) if (i < P.n) uq_glds16(P.src[i], P.dst[i]);
+    }
     if (tid < C) reinterpret_cast<float*>(smem + UQ_BIAS_BASE)[tid] = a.bias[tid];
-    uq_stage_barrier();
+    uq_stage_barrier<0>();
     int buf = 0, stage_no = 0;
+    bool pre_issued = false;              // the next stage's pieces are already on their way (issued by the previous item's epilogue)
 
     for (int t = 0; t < n_items; ++t) {
         const PersistItem it = cs.it;
@@ -213,7 +236,12 @@ __global__ __launch_bounds__(UQ_THREADS) void conv_upq_kernel(ConvArgs a) {
         // one pipeline stage: NTAPS taps of 2 k-steps on the pair in use while the next stage's tile and slab land in the other
         // (ONE k-loop per loop body: two variants under a branch make the accumulators PHIs that hipcc copies and spills)
         auto stage = [&](auto ntaps_tag) __attribute__((always_inline)) {
-            if (stage_no + 1 < S) dma_stage(cn, buf ^ 1);
+            Plan P;
+            P.n = 0;
+            if (stage_no + 1 < S && !pre_issued) {
+                if (cn.kc == 0) item_offsets(cn.it);
+                plan_stage(cn, buf ^ 1, P);
+            }
             const unsigned char* ib = smem;
             const unsigned char* wb = smem + UQ_W_BASE + buf * UQ_SLAB_BYTES + b_off;
             // NS k-steps (tap, k) x 4 weight fragments x 2 pixel rows; fragments rotate through two weight registers and two pairs of pixel
@@ -226,6 +254,8 @@ __global__ __launch_bounds__(UQ_THREADS) void conv_upq_kernel(ConvArgs a) {
                 auto rd_a = [&](int st, int m) __attribute__((always_inline)) -> bf16x8_t {
                     return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ib + (a_off[m][st >> 1] ^ ((st & 1) << 5))));
                 };
+#pragma unroll 1
+                for (int rep = 0; rep < ((UQ_ABL & 64) ? 2 : 1); ++rep) {       // (ablation 64: the k-loop twice per stage -- what does a k-loop cost by itself?)
                 bf16x8_t bq[2], aq[2][2];
                 bq[0] = rd_b(0, 0);
                 aq[0][0] = rd_a(0, 0); aq[0][1] = rd_a(0, 1);
@@ -234,6 +264,10 @@ __global__ __launch_bounds__(UQ_THREADS) void conv_upq_kernel(ConvArgs a) {
 #pragma unroll
                     for (int j = 0; j < NTL; ++j) {
                         const int g = st * NTL + j;
+                        // the next stage's DMA pieces, spread over the k-loop: piece i rides in front of MFMA pair (i NG) / 10
+#pragma unroll
+                        for (int i = 0; i < 10; ++i)
+                            if ((i * NG) / 10 == g && i < P.n && !(((UQ_ABL & 8) && (i < 4 || i >= P.n - (wv < 4 ? 1 : 0))) || ((UQ_ABL & 16) && i >= 4 && i < P.n - (wv < 4 ? 1 : 0)))) uq_glds16(P.src[i], P.dst[i]);
                         if (g + 1 < NG) bq[(g + 1) & 1] = rd_b((g + 1) / NTL, (g + 1) % NTL);
                         if (st + 1 < NS && j == 1) aq[(st + 1) & 1][0] = rd_a(st + 1, 0);
                         if (st + 1 < NS && j == 2) aq[(st + 1) & 1][1] = rd_a(st + 1, 1);
@@ -242,6 +276,11 @@ __global__ __launch_bounds__(UQ_THREADS) void conv_upq_kernel(ConvArgs a) {
                         for (int m = 0; m < 2; ++m) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[g & 1], aq[st & 1][m], acc[m][j], 0, 0, 0);   // D[cout][pixel]
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                }
+            }
+            if constexpr (UQ_ABL & 4) {
+#pragma unroll
+                for (int i = 0; i < 10; ++i) if (i < P.n) uq_glds16(P.src[i], P.dst[i]);
             }
             {   // the fragment addresses move to the other tile
                 const int step = buf ? -UQ_TILE_BYTES : UQ_TILE_BYTES;
@@ -253,22 +292,34 @@ __global__ __launch_bounds__(UQ_THREADS) void conv_upq_kernel(ConvArgs a) {
             buf ^= 1;
             ++stage_no;
             cs = cn; cn = cursor.next();
-            uq_stage_barrier();              // the next stage is staged; nobody reads this stage's pair any more
+            // the next stage is staged; nobody reads this stage's pair any more
+            if (pre_issued) uq_stage_barrier<16>(); else uq_stage_barrier<0>();
+            pre_issued = false;
             flush_stats();
         };
 #pragma unroll 1
         for (int kc = 0; kc < NKC; ++kc) stage(std::integral_constant<int, 4>{});
 #pragma unroll 1
         for (int kc = NKC; kc < NST; ++kc) stage(std::integral_constant<int, 1>{});
-        // ---- epilogue: conv_pk.hip's line-coalesced form.  The patch is this wave's own DMA region of the tile buffer the last stage
-        // just finished with (pair buf ^ 1): the wave restages it itself, at the top of the next stage, i.e. behind this epilogue.
+        // ---- epilogue: conv_pk.hip's line-coalesced form in 8-pixel passes through a 2-KB patch of the wave's own, so that both buffers of
+        // the other pair are free NOW: the pieces of the stage after next (the next item's stage 1) are issued first, the stores behind them.
+        if (stage_no + 1 < S) {
+            Plan P;
+            plan_stage(cn, buf ^ 1, P);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) if (i < P.n) uq_glds16(P.src[i], P.dst[i]);
+            pre_issued = true;
+        }
         if constexpr (UQ_ABL & 2) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int j = 0; j < NTL; ++j) asm volatile("" :: "v"(acc[m][j]));
+            if (pre_issued) {       // keep the counted wait honest: 16 dummy-free -- no stores were issued, so wait for everything
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         } else {
-            unsigned char* patch = smem + (buf ^ 1) * UQ_TILE_BYTES + wave * UQ_PATCH_BYTES;
+            unsigned char* patch = smem + UQ_PATCH_BASE + wave * UQ_PATCH_BYTES;
             const int pa = it.nb >> 1, pb = it.nb & 1;
             int l_e = lane, w_e = wave;
             asm volatile("" : "+v"(l_e), "+v"(w_e));
@@ -286,9 +337,9 @@ __global__ __launch_bounds__(UQ_THREADS) void conv_upq_kernel(ConvArgs a) {
             const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.Hout * a.Wout * (2 * C), 0x00020000);
             const unsigned cstep = (unsigned)(2 * C) * 8u;                    // bytes per read-back's 4 low-res pixels = 8 output pixels
             const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
-            const int r16 = l_e & 15, qh = (l_e >> 4) & 1;                    // writer: pixel r = 16 qh + r16 of the row, half h
+            const int r8 = l_e & 7, eg = (l_e >> 3) & 3;                      // writer: pixel r = 8 eg + r8 of the row, half h
             const int h_e = l_e >> 5;
-            const int pq = l_e >> 4, cc_r = l_e & 15;                         // reader: pixel 4 k + pq of the half-row, chunk cc_r (8 couts)
+            const int pq = l_e >> 4, cc_r = l_e & 15;                         // reader: pixel 4 k + pq of the 8-pixel group, chunk cc_r (8 couts)
             constexpr int PITCH = NT * 2;
             u32x4_t pkd[2][NTL * 2];
 #pragma unroll
@@ -305,18 +356,18 @@ __global__ __launch_bounds__(UQ_THREADS) void conv_upq_kernel(ConvArgs a) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
+                for (int e = 0; e < 4; ++e) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (qh == q) {
+                    if (eg == e) {
 #pragma unroll
                         for (int g = 0; g < NTL * 2; ++g) {
                             const int cc = 2 * g + h_e;                       // chunk of the pixel's 128-cout run: couts 8 cc .. 8 cc + 7
-                            *reinterpret_cast<u32x4_t*>(patch + r16 * PITCH + ((cc ^ r16) << 4)) = pkd[m][g];
+                            *reinterpret_cast<u32x4_t*>(patch + r8 * PITCH + ((cc ^ r8) << 4)) = pkd[m][g];
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < 2; ++k) {
                         const int p = 4 * k + pq;
                         const u32x4_t v = *reinterpret_cast<const u32x4_t*>(patch + p * PITCH + ((cc_r ^ p) << 4));
                         const unsigned w[4] = {v.x, v.y, v.z, v.w};
@@ -327,9 +378,9 @@ __global__ __launch_bounds__(UQ_THREADS) void conv_upq_kernel(ConvArgs a) {
                             s1 = __builtin_amdgcn_fdot2_f32_bf16(bv, ones, s1, false);
                             q1 = __builtin_amdgcn_fdot2_f32_bf16(bv, bv, q1, false);
                         }
-                        const bool ok = trow[m] && lcol0 + 16 * q + 4 * k < a.Win;
+                        const bool ok = trow[m] && lcol0 + 8 * e + 4 * k < a.Win;
                         ssum += ok ? s1 : 0.f; qsum += ok ? q1 : 0.f;
-                        __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ok ? toffs[m] + (unsigned)(4 * q + k) * cstep : 0xffffffffu, 0, IRE_ST_LINE);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ok ? toffs[m] + (unsigned)(2 * e + k) * cstep : 0xffffffffu, 0, IRE_ST_LINE);
                     }
                 }
             // this lane's chunk cc_r over its read-backs; the other lanes with the same chunk sit 16 apart
@@ -337,7 +388,6 @@ __global__ __launch_bounds__(UQ_THREADS) void conv_upq_kernel(ConvArgs a) {
             ssum = uq_swap32_add(ssum); qsum = uq_swap32_add(qsum);
             if (l_e < 16) *reinterpret_cast<float2*>(red + red_par * (8 * 32) + (wave * 16 + cc_r) * 2) = make_float2(ssum, qsum);
             st_img = it.img; st_slot = it.tile * 4 + it.nb; st_par = red_par; red_par ^= 1;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the patch reads are done before this wave's next DMA pieces may land on it
         }
     }
     __syncthreads();                     // the last item's chunk sums
