@@ -27,6 +27,7 @@ SOURCES = [
      (["-DIRE_UP_D=" + os.environ["IRE_UP_D"]] if os.environ.get("IRE_UP_D") else []) +
      (["-DIRE_UP_TEPI=" + os.environ["IRE_UP_TEPI"]] if os.environ.get("IRE_UP_TEPI") else [])),
     ("conv_upq.hip", os.environ.get("UQ_DEFS", "").split()),
+    ("conv_dnq.hip", os.environ.get("DQ_DEFS", "").split()),
     ("conv_down.hip", (["-DDN_LD_NT=" + os.environ["DN_LD_NT"]] if os.environ.get("DN_LD_NT") else [])),
     ("conv_stem.hip", []),
     ("conv_f8.hip", []),

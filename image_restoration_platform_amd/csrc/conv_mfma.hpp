@@ -136,6 +136,9 @@ void conv_up_subpixel_launch(const ConvArgs& a, hipStream_t stream);
 // The fused `up` + `fuse` with cout = 128 as parity-major items (conv_upq.hip): a.w = d_wuq, a.w1 = d_wsq, a.nkc = Cin / 32, a.nblocks = 4
 // (parities), 16 x 32 LOW-res tiles, a.zeros, partials [img][tile * 4 + parity][8][2] (four rows per low-res tile).
 void conv_upq_launch(const ConvArgs& a, hipStream_t stream);
+// CONV_DOWN with cout = 128 / 256 as all-DMA 128-cout items (conv_dnq.hip): a.w = d_wdq, a.nkc = Cin / 32, a.nblocks = cout / 128, a.zeros;
+// tiles, partials layout and strip arguments as conv_down_launch.
+void conv_dnq_launch(const ConvArgs& a, hipStream_t stream);
 // CONV_UP through the same pipelined kernel (Hin/Win = low-res source, Hout/Wout = 2x; a.stats = nullptr).
 void conv_up_launch(const ConvArgs& a, hipStream_t stream);
 

@@ -394,6 +394,7 @@ __global__ __launch_bounds__(UQ_THREADS) void conv_upq_kernel(ConvArgs a) {
     flush_stats();
 }
 
+
 }  // namespace
 
 // a.in0 = low-res input [img][in_rows][Win][Cin], a.in1 = skip [img][Hout][Wout][128] at its first real row, a.out likewise;

@@ -95,6 +95,7 @@ Engine::Engine(const ire_config& cfg) {
     if (const char* v = std::getenv("IRE_PC")) pc_split_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_PK")) use_pk_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_UPQ")) use_upq_ = std::atoi(v);
+    if (const char* v = std::getenv("IRE_DNQ")) use_dnq_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_HEAD_RB")) head_rb_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_DOWN_RB")) down_rb_ = std::atoi(v);
     if (const char* v = std::getenv("IRE_STEM_RB")) stem_rb_ = std::atoi(v);
@@ -311,6 +312,30 @@ ConvW Engine::make_conv(ConvKind kind, const std::string& wname, const std::stri
         c.d_wd = (unsigned short*)dalloc(arrd.size() * 2);
         net_.allocs.push_back(c.d_wd);
         IRE_HIP(hipMemcpy(c.d_wd, arrd.data(), arrd.size() * 2, hipMemcpyHostToDevice));
+        if (cout % 128 == 0) {
+            // conv_dnq.hip: the same taps in the same phase order as 128-cout slabs: [n-block of 128][kc32][9 taps][c8][128 permuted rows][8]
+            std::vector<unsigned short> arrq((size_t)(cout / 128) * nkd * 9 * 4 * 128 * 8, 0);
+            size_t qpos = 0;
+            for (int nb = 0; nb < cout / 128; ++nb)
+                for (int kc = 0; kc < nkd; ++kc)
+                    for (int ph = 0; ph < 4; ++ph) {
+                        const int pa = ph >> 1, pb = ph & 1, nty = pa ? 2 : 1, ntx = pb ? 2 : 1;
+                        for (int t = 0; t < nty * ntx; ++t) {
+                            const int ty = t / ntx, tx = t % ntx;
+                            const int ky = pa ? (ty ? 2 : 0) : 1, kx = pb ? (tx ? 2 : 0) : 1;
+                            for (int c8 = 0; c8 < 4; ++c8)
+                                for (int n = 0; n < 128; ++n)
+                                    for (int e = 0; e < 8; ++e) {
+                                        const int co = nb * 128 + perm(n), ci = kc * 32 + c8 * 8 + e;
+                                        arrq[qpos++] = f32_to_bf16(W[((size_t)co * cin + ci) * 9 + ky * 3 + kx]);
+                                    }
+                        }
+                    }
+            if (!d_zero_) { d_zero_ = dalloc(256); IRE_HIP(hipMemset(d_zero_, 0, 256)); }
+            c.d_wdq = (unsigned short*)dalloc(arrq.size() * 2);
+            net_.allocs.push_back(c.d_wdq);
+            IRE_HIP(hipMemcpy(c.d_wdq, arrq.data(), arrq.size() * 2, hipMemcpyHostToDevice));
+        }
     }
     if (kind == CONV_UP && cin % 64 == 0 && cout % 32 == 0) {
         // conv_up.hip: nearest x2 -> 3x3 == four 2x2 convolutions on the low-res grid, one per output parity (pa, pb); the taps that
@@ -973,10 +998,11 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     const bool up_rb = (cw.kind == CONV_UP) && rb_tile_h_ == kRbTileH && cw.cout >= up_rb_min_c_;
     const bool up_sub = up_rb && up_subpixel_ && cw.d_wu != nullptr;       // sub-pixel form: tiles and halo rows on the LOW-res grid
     const bool up_fused = up_sub && op.in1 != BUF_NONE;                     // composed with the 1x1 `fuse` (build_program)
-    // cout = 128: parity-major items with all 128 couts (conv_upq.hip); four partial rows per low-res tile.  (fp8 engines and every
+    // cout = 128: parity-major items with all 128 couts (conv_upq.hip); four partial rows per low-res tile.  The cout = 64 level stays on
+    // conv_up.hip: its row-parity form of this kernel measured 278 us against 241 (profiles/r04_experiments.md).  (fp8 engines and every
     // other level: conv_up.hip.)  A function of the layer only: batch / strip invariance holds.
     const bool up_q = up_fused && use_upq_ && cw.d_wuq != nullptr && cw.cout == 128 && cw.cin % 32 == 0;
-    const int parts_mul = up_q ? 4 : 1;
+    const int parts_mul = up_q ? 4 : 1;     // partial rows per low-res tile: one per item (parity)
     const bool head_rb = cw.kind == CONV_HEAD && rb_tile_h_ == kRbTileH && head_rb_ && cw.d_wp != nullptr;    // the head on the pipelined kernel
     const bool down_rb = cw.kind == CONV_DOWN && rb_tile_h_ == kRbTileH && down_rb_ && cw.d_wd != nullptr;    // stride-2 convs by pixel phase
     const bool stem_rb = cw.kind == CONV_STEM && rb_tile_h_ == kRbTileH && stem_rb_ && cw.d_wstem != nullptr && op.stats_out;  // the stem on its own kernel
@@ -1066,10 +1092,14 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
             conv_w4_launch(cw.kind == CONV_RB2, a, R.stream); kname = "conv_w4";
         }
     } else if (head_rb) { a.w = cw.d_wp; if (pc_split_ & 1) { conv_pc_launch(false, true, a, R.stream); kname = "conv_pc"; } else { conv_head_launch(a, R.stream); kname = "conv_rb"; } }
+    else if (down_rb && use_dnq_ && cw.d_wdq != nullptr) {
+        a.w = cw.d_wdq; a.nkc = cw.cin / 32; a.nblocks = cw.cout / 128; a.zeros = d_zero_;
+        conv_dnq_launch(a, R.stream); kname = "conv_dnq";
+    }
     else if (down_rb) { a.w = cw.d_wd; a.nkc = cw.cin / 32; a.nblocks = cw.cout / 64; conv_down_launch(a, R.stream); kname = "conv_down"; }
     else if (stem_rb) { a.w = cw.d_wstem; conv_stem_launch(a, R.stream); kname = "conv_stem"; }
     else if (up_q) {
-        a.w = cw.d_wuq; a.w1 = cw.d_wsq; a.bias = cw.d_bias_uf; a.nkc = cw.cin / 32; a.nblocks = 4;
+        a.w = cw.d_wuq; a.w1 = cw.d_wsq; a.bias = cw.d_bias_uf; a.nkc = cw.cin / 32; a.nblocks = parts_mul;
         a.in1 = in_ptr(op.in1) + (size_t)g.halo * Wout * cw.cout;
         a.cin1 = cw.cout; a.zeros = d_zero_;
         conv_upq_launch(a, R.stream); kname = "conv_upq";

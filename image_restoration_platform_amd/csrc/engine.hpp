@@ -35,6 +35,7 @@ struct ConvW {
     unsigned short* d_wu = nullptr;  // CONV_UP as a sub-pixel conv (conv_up.hip): [nblock32][kc32][parity][kk][32][8], taps pre-summed per parity
     // CONV_UP composed with the level's 1x1 `fuse` (engine.cpp::make_up_fused; conv_up.hip fused form)
     unsigned short* d_wuf = nullptr; // sub-pixel slabs of (Wf_up . Wup), layout of d_wu
+    unsigned short* d_wdq = nullptr; // conv_dnq.hip (stride-2 convs with cout % 128 == 0): d_wd's taps as 128-cout slabs
     unsigned short* d_wuq = nullptr; // conv_upq.hip (cout = 128): the same composed weights as [parity][kc32][tap4][c8][128 permuted rows][8]
     unsigned short* d_wsq = nullptr; // conv_upq.hip: skip half of the fuse weights as [ks32][c8][128 permuted rows][8]
     unsigned short* d_wsk = nullptr; // skip half of the fuse weights as MFMA A fragments: [nblock32][ks = C/16][h][32 permuted rows][8]
@@ -223,6 +224,7 @@ private:
     uint32_t flags_ = 0;
     int precision_ = IRE_PRECISION_BF16;
     int w4_split_ = 1;            // IRE_W4_SPLIT=0: never use the 64-cout items
+    int use_dnq_ = 1;             // the stride-2 convs with cout >= 128 as all-DMA 128-cout items on conv_dnq.hip (IRE_DNQ=0: conv_down.hip)
     int use_upq_ = 1;             // the level-2 `up` + `fuse` (cout = 128) as parity-major 128-cout items on conv_upq.hip (IRE_UPQ=0: conv_up.hip)
     int use_pk_ = 1;              // C >= 128 ResBlock convs (128-cout items, fused activation) on conv_pk.hip's producer / consumer workgroups: 1 = the convs without a residual, 2 = all (IRE_PK=0: conv_w4.hip)
     int use_w4_ = 1;              // C >= 128 ResBlock convs on conv_w4.hip (IRE_W4=0: conv_rb.hip)

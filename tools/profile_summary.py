@@ -29,7 +29,7 @@ def stats(src, dst, title, footer=""):
 def is_conv3x3(name):
     if "conv_rb_kernel" in name or "conv_pc_kernel" in name:   # the HEAD instantiation (last template argument true) is its own family
         return not name.rstrip().endswith(", true>(ire::ConvArgs)")
-    if "conv_w4_kernel" in name or "conv_up_kernel" in name or "conv_down_kernel" in name or "conv_f8_kernel" in name or "conv_pk_kernel" in name or "conv_upq_kernel" in name:
+    if "conv_w4_kernel" in name or "conv_up_kernel" in name or "conv_down_kernel" in name or "conv_f8_kernel" in name or "conv_pk_kernel" in name or "conv_upq_kernel" in name or "conv_dnq_kernel" in name:
         return True
     if "conv_mfma_kernel<4, 9," in name and not name.rstrip().endswith("true>(ire::ConvArgs)"):   # last arg = HEAD: its own family
         return True
@@ -67,8 +67,10 @@ def group_of(name, k):
         if lvl is None:
             return None
         return "L%d.rb%d" % (lvl, 2 if args[1] == "true" else 1)
-    if "conv_down_kernel" in n:
-        return "down%d" % (k % 3)
+    if "conv_dnq_kernel<" in n:         # conv_dnq_kernel<COUT>: the width is the level
+        return {"128": "down1", "256": "down2"}.get(n[n.find("<") + 1:n.find(">")])
+    if "conv_down_kernel" in n:         # default schedule: only down0 (IRE_DNQ=0: all three, in level order)
+        return "down0"
     if "conv_up_kernel<" in n:
         return {"2": "up0", "4": "up1", "8": "up2"}.get(n[n.find("<") + 1:n.find(">")])
     if "conv_upq_kernel" in n:
@@ -92,7 +94,7 @@ def traffic(fetch_csv, write_csv, dst, steps):
     out = {
         "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile",
         "unit_note": "counters are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); WRITE_SIZE as is",
-        "family": "conv3x3 (conv_pc_kernel / conv_rb_kernel without their HEAD instantiation, conv_w4_kernel, conv_f8_kernel, conv_up_kernel, conv_upq_kernel, conv_down_kernel; the v1 stride-2 conv_mfma_kernel instantiation where a switch selects it)",
+        "family": "conv3x3 (conv_pc_kernel / conv_rb_kernel without their HEAD instantiation, conv_w4_kernel, conv_f8_kernel, conv_up_kernel, conv_upq_kernel, conv_dnq_kernel, conv_down_kernel; the v1 stride-2 conv_mfma_kernel instantiation where a switch selects it)",
         "per_kernel": {},
     }
     tot_f = tot_w = 0.0
