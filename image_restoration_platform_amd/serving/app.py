@@ -8,7 +8,8 @@ with the endpoints its docs sketch (image-restoration-platform.md:1076-1127):
   POST /fuse      JSON {"images": [base64, ...2..3], "prompt": "..."}                 -> {base64Image, metadata}
   POST /restore_batch  JSON {"images": [base64, ...], "prompt": "..."}                -> [RestoratorService envelope, ...] in order
                   restoreBatch (restorator.js:181-236) through the PyTorch-ROCm extension (torch_host.TorchEngine): images of
-                  one shape are stacked into ONE uint8 tensor, classified and restored as one engine batch on the GPU
+                  one shape are stacked into ONE uint8 tensor, classified and restored as one engine batch on the GPU, and
+                  (widths that are multiples of 8, no crop) their base64 PNG texts are written on the device too
   GET  /health/ready                                                                 -> service + engine health
 The engine is created on first use; without a gfx950 device every compute endpoint answers 503 with the
 engine's "service unavailable" message (there is no CPU fallback).
@@ -150,7 +151,13 @@ async def restore_batch(request: Request):
                 else:
                     scores = torch.cat([te.classify(torch.from_numpy(decoded[i][3][None]).cuda(), jp[k:k + 1])[0] for k, i in enumerate(chunk)])
                 t1 = time.time()
-                out = te.restore(x, scores, None).cpu().numpy()
+                restored = te.restore(x, scores, None)
+                # the result text on the device when the chunk's images need no crop (csrc/encode.hip through the extension):
+                # the D2H copy carries base64 characters, the host encodes nothing
+                texts = None
+                if same and restored.shape[2] % 8 == 0:
+                    texts = te.encode_png_base64(restored).cpu().numpy()
+                out = restored.cpu().numpy() if texts is None else None
                 sc = scores.cpu().numpy()
                 t2 = time.time()
             except EngineError as e:
@@ -162,7 +169,8 @@ async def restore_batch(request: Request):
                 h, w = decoded[i][1]
                 degradation = {key: float(sc[k, j]) for j, key in enumerate(KEYS)}
                 results[i] = {
-                    "success": True, "restoredImage": encode_png_base64(np.ascontiguousarray(out[k, :h, :w])),
+                    "success": True, "restoredImage": (texts[k].tobytes().decode("ascii") if texts is not None
+                                                       else encode_png_base64(np.ascontiguousarray(out[k, :h, :w]))),
                     "degradationAnalysis": degradation,
                     "enhancedPrompt": enhancer.enhance(degradation=degradation, user_prompt=payload.get("prompt"), options={"batchIndex": i, "batchSize": len(bufs)}),
                     "timings": {"classify_ms": int(1e3 * (t1 - t0)), "prompt_ms": 0, "restore_ms": int(1e3 * (t2 - t1)), "total_ms": int(1e3 * (t2 - t0))},

@@ -77,5 +77,20 @@ class TorchEngine:
     def fuse(self, views_u8, noise_score=-1.0):
         return self._call(self._ext.fuse, views_u8, float(noise_score))
 
+    def fuse_batch(self, views_u8, noise_scores=None):
+        """views [S,k,H,W,3] uint8 cuda (S <= 16 view sets of one shape) -> (fused [S,H,W,3], shifts [S,k,2]); noise_scores: S floats (None / < 0: classify inside)."""
+        import torch
+        s = int(views_u8.shape[0])
+        ns = torch.full((s,), -1.0, dtype=torch.float64) if noise_scores is None else torch.as_tensor([float(x) for x in noise_scores], dtype=torch.float64)
+        return self._call(self._ext.fuse_batch, views_u8, ns)
+
+    def preprocess(self, rgb_u8, orientation=1, max_dim=2048):
+        """stored pixels [H,W,3] uint8 cuda -> upright pixels fitted inside max_dim (imagePreprocess.js:24-91, pixel part)."""
+        return self._call(self._ext.preprocess, rgb_u8, int(orientation), int(max_dim))
+
+    def encode_png_base64(self, rgb_u8):
+        """[N,H,W,3] uint8 cuda -> [N, chars] uint8 cuda: the base64 text of each image's PNG file, written on the device."""
+        return self._call(self._ext.encode_png_base64, rgb_u8)
+
     def restore_tiled(self, rgb_u8, nstrips, scores=None, is_jpeg_u8=None):
         return self._call(self._ext.restore_tiled, rgb_u8, int(nstrips), scores, is_jpeg_u8)

@@ -56,5 +56,8 @@ def test_restore_and_fuse_endpoints():
     assert r.status_code == 200, r.text
     res = r.json()
     assert [x["success"] for x in res] == [True, True, True, False] and res[3]["error"]["type"] == "INVALID_INPUT"
-    assert res[0]["restoredImage"] == j["restoredImage"] and res[0]["degradationAnalysis"] == j["degradationAnalysis"]
+    # (the batch endpoint's text is the device-encoded PNG -- stored deflate blocks --, the single-image endpoint's the host codec's: same pixels)
+    px = lambda t: np.asarray(Image.open(io.BytesIO(base64.b64decode(t))).convert("RGB"))
+    assert np.array_equal(px(res[0]["restoredImage"]), px(j["restoredImage"])) and res[0]["degradationAnalysis"] == j["degradationAnalysis"]
+    assert px(res[1]["restoredImage"]).shape == (64, 64, 3)
     assert res[1]["timings"].keys() == {"classify_ms", "prompt_ms", "restore_ms", "total_ms"}

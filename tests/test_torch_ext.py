@@ -12,7 +12,7 @@ def test_extension_is_built_and_loads_and_fails_loudly_without_gpu():
     import torch
     assert os.path.exists(torch_host.EXT_PATH), "run __graft_entry__.build()"
     ext = torch_host.load_extension()
-    for name in ("init", "shutdown", "classify", "restore", "fuse", "restore_tiled"):
+    for name in ("init", "shutdown", "classify", "restore", "fuse", "restore_tiled", "fuse_batch", "preprocess", "encode_png_base64"):
         assert hasattr(ext, name)
     if not torch.cuda.is_available():
         from image_restoration_platform_amd.engine import EngineError
@@ -48,6 +48,25 @@ def test_extension_matches_the_ctypes_host(engine):
         w1 = te.restore(img[None])[0]
         torch.cuda.synchronize()
         assert torch.equal(t1, w1)
+        # the three entry points added in round 4: batched fusion, the preprocess step, the device-side PNG + base64 text
+        vb = torch.from_numpy(np.ascontiguousarray(np.stack([synth.fusion_views(64, 72, seed=5 + i) for i in range(3)]))).cuda()
+        fb1, sb1 = te.fuse_batch(vb, [0.1, -1.0, 0.3])
+        fb0, sb0 = engine.fuse_batch_tensor(vb, [0.1, -1.0, 0.3])
+        torch.cuda.synchronize()
+        assert torch.equal(fb1, fb0) and torch.equal(sb1, sb0)
+        big = torch.from_numpy(synth.batch(1, 120, 200, start=62)[0]).cuda()
+        p1 = te.preprocess(big, orientation=6, max_dim=96)
+        p0 = engine.preprocess_tensor(big, orientation=6, max_dim=96)
+        torch.cuda.synchronize()
+        assert p1.shape == p0.shape and torch.equal(p1, p0)
+        e1 = te.encode_png_base64(x)
+        e0 = engine.encode_png_base64_tensor(x)
+        torch.cuda.synchronize()
+        assert torch.equal(e1, e0)
+        import base64, io
+        from PIL import Image
+        png = base64.b64decode(bytes(e1[1].cpu().numpy()))
+        assert np.array_equal(np.asarray(Image.open(io.BytesIO(png)).convert("RGB")), x[1].cpu().numpy())
         with torch.cuda.stream(torch.cuda.Stream()):            # the extension follows the CURRENT torch stream
             d = te.restore(x, None, jp)
         torch.cuda.synchronize()
