@@ -108,20 +108,6 @@ __global__ __launch_bounds__(256) void classifier_scan_kernel(const uint8_t* __r
     const int img = blockIdx.y;
     const uint8_t* base = rgb + (size_t)img * H * W * 3;
 
-    // tables -> LDS once per workgroup (pre-multiplied by the luminance weights x10000)
-    {
-        unsigned int l = g_lin16[tid];
-        L.wR[tid] = 2126u * l;
-        L.wG[tid] = 7152u * l;
-        L.wB[tid] = 722u * l;
-        L.thr[tid] = g_thr[tid];
-        if (tid == 0) L.thr[256] = g_thr[256];
-        // 5008 bytes as 313 16-byte chunks (hipMalloc'd: aligned; the table is padded to 5008 on the host)
-        const uint4* gi = reinterpret_cast<const uint4*>(g_inv);
-        uint4* li = reinterpret_cast<uint4*>(L.inv);
-        for (int i = tid; i < 5008 / 16; i += 256) li[i] = gi[i];
-    }
-    __syncthreads();
 
     unsigned long long acc[CLS_NSUMS];
 #pragma unroll
@@ -173,6 +159,21 @@ __global__ __launch_bounds__(256) void classifier_scan_kernel(const uint8_t* __r
         }
     };
     if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+    // (the first tile's pixels are requested BEFORE the tables: the two round trips overlap)
+    // tables -> LDS once per workgroup (pre-multiplied by the luminance weights x10000)
+    {
+        unsigned int l = g_lin16[tid];
+        L.wR[tid] = 2126u * l;
+        L.wG[tid] = 7152u * l;
+        L.wB[tid] = 722u * l;
+        L.thr[tid] = g_thr[tid];
+        if (tid == 0) L.thr[256] = g_thr[256];
+        // 5008 bytes as 313 16-byte chunks (hipMalloc'd: aligned; the table is padded to 5008 on the host)
+        const uint4* gi = reinterpret_cast<const uint4*>(g_inv);
+        uint4* li = reinterpret_cast<uint4*>(L.inv);
+        for (int i = tid; i < 5008 / 16; i += 256) li[i] = gi[i];
+    }
+    __syncthreads();
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         const int y0 = ty * CT_H, x0 = tx * CT_W;
@@ -343,20 +344,80 @@ __global__ __launch_bounds__(256) void classifier_scan_kernel(const uint8_t* __r
     }
     __syncthreads();
     __shared__ float s_cond[8];
-    if (tid == 0) {
-        __hip_atomic_store(&tickets[img], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-cleaning: the next launch starts from zero without a memset
-        uint64_t S[CLS_NSUMS];
-        for (int k = 0; k < CLS_NSUMS; ++k) S[k] = red[0][k];
-        double sc[7];
-        int32_t lb;
-        cls_finalize_one(S, (uint64_t)H * (uint64_t)W, is_jpeg ? is_jpeg[img] : 1, sc, &lb);
-        for (int k = 0; k < 7; ++k) {
-            if (scores) scores[(size_t)img * 7 + k] = sc[k];
-            if (cond) cond[(size_t)img * 8 + k] = (float)sc[k];
-            s_cond[k] = (float)sc[k];
+    // The scores (classifier_finalize.hpp::cls_finalize_one, the same IEEE steps expression by expression) spread over the last
+    // workgroup's four waves: one thread walking all of it is ~7 double square roots and ~20 double divisions in one dependent chain
+    // (9.5 of the scan's 46 us at batch 8: the launch's tail).  Lanes of one wave that run DIFFERENT formulas serialise, so the
+    // independent pieces go to different waves, and pieces with the same formula to different lanes of one wave:
+    //   step 1: wave 0 lanes 0..2 mean / sample stdev of R, G, B; wave 1 lanes 0..3 the four exact population variances
+    //   step 2: wave 0 noise, wave 1 fade, wave 2 colorShift, wave 3 blur / lowLight / compression / scratch
+    //   step 3: thread 0 the label (first-max argmax), the ticket's reset
+    {
+#pragma clang fp contract(off)
+        __shared__ double f_mean[3], f_sd[3], f_var[4], f_sc[8];
+        const int wave_f = tid >> 6, lane_f = tid & 63;
+        const uint64_t px = (uint64_t)H * (uint64_t)W;
+        const int jpeg = is_jpeg ? is_jpeg[img] : 1;
+        if (wave_f == 0 && lane_f < 3) {
+            const double vals = (double)px;
+            const double ds = (double)red[0][lane_f], ds2 = (double)red[0][3 + lane_f];
+            f_mean[lane_f] = ds / vals;
+            f_sd[lane_f] = sqrt(fabs(ds2 - (ds * ds / vals)) / (vals - 1.0));
+        } else if (wave_f == 1 && lane_f < 4) {
+            // var_e8, var_e9, var_rgb, var_blur
+            const uint64_t n = lane_f < 2 ? px : 3 * px;
+            const uint64_t sa = lane_f == 0 ? red[0][8] : lane_f == 1 ? red[0][10] : lane_f == 2 ? red[0][0] + red[0][1] + red[0][2] : red[0][6];
+            const uint64_t sb = lane_f == 0 ? red[0][9] : lane_f == 1 ? red[0][11] : lane_f == 2 ? red[0][3] + red[0][4] + red[0][5] : red[0][7];
+            f_var[lane_f] = popvar_exact(n, sa, sb);
         }
-        if (cond) cond[(size_t)img * 8 + 7] = 0.f;
-        if (label) label[img] = lb;
+        __syncthreads();
+        if (lane_f == 0) {
+            if (wave_f == 0) {
+                f_sc[1] = js_min(sqrt(f_var[1]) / 50.0, 1.0);
+            } else if (wave_f == 1) {
+                const double sd0 = f_sd[0], sd1 = f_sd[1], sd2 = f_sd[2];
+                const double sat = sqrt((sd0 * sd0 + sd1 * sd1) + sd2 * sd2) / 255.0;
+                const double colorfulness = js_min(sat, 1.0);
+                const double avg_sd = (((0.0 + sd0) + sd1) + sd2) / 3.0;
+                const double contrast = js_min(avg_sd / 64.0, 1.0);
+                f_sc[5] = js_min((1.0 - colorfulness) * 0.6 + (1.0 - contrast) * 0.4, 1.0);
+            } else if (wave_f == 2) {
+                const double m0 = f_mean[0], m1 = f_mean[1], m2 = f_mean[2];
+                const double avg = ((m0 + m1) + m2) / 3.0;
+                const double dr = avg > 0 ? fabs(m0 - avg) / avg : 0.0;
+                const double dg = avg > 0 ? fabs(m1 - avg) / avg : 0.0;
+                const double db = avg > 0 ? fabs(m2 - avg) / avg : 0.0;
+                f_sc[6] = js_min(js_max(js_max(dr, dg), db) * 2.0, 1.0);
+            } else {
+                const double nv = js_min(f_var[0] / 1000.0, 1.0);
+                f_sc[0] = js_max(0.0, 1.0 - nv);
+                const double mb = (((0.0 + f_mean[0]) + f_mean[1]) + f_mean[2]) / 3.0;
+                const double nb = mb / 255.0;
+                f_sc[2] = (nb < 0.3) ? js_min((0.3 - nb) * 2.0, 1.0) : 0.0;
+                if (!jpeg) {
+                    f_sc[3] = 0.0;
+                } else {
+                    const double delta = js_max(0.0, f_var[2] - f_var[3]);
+                    f_sc[3] = js_min(js_min(delta / 500.0, 1.0), 1.0);
+                }
+                const double total = (double)(red[0][12] + red[0][13]);
+                f_sc[4] = js_min(js_min(total / 1000.0, 1.0), 1.0);
+            }
+        }
+        __syncthreads();
+        if (tid < 7) {
+            const double v = f_sc[tid];
+            if (scores) scores[(size_t)img * 7 + tid] = v;
+            if (cond) cond[(size_t)img * 8 + tid] = (float)v;
+            s_cond[tid] = (float)v;
+        }
+        if (tid == 0) {
+            __hip_atomic_store(&tickets[img], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-cleaning: the next launch starts from zero without a memset
+            if (cond) cond[(size_t)img * 8 + 7] = 0.f;
+            int best = 0;                    // first-max argmax in key order
+            for (int i = 1; i < 7; ++i)
+                if (f_sc[i] > f_sc[best]) best = i;
+            if (label) label[img] = best;
+        }
     }
     if (film == nullptr) return;
     // the restoration's FiLM vector of this image (Linear(7 -> film_n)(scores): gn.hip::film_kernel's arithmetic, term by term) from the
