@@ -31,8 +31,11 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
+#ifndef DQ_ST
+#define DQ_ST IRE_ST_LINE   // cache policy of the output stores (conv_mfma.hpp): build-time A/B
+#endif
 #ifndef DQ_ABL
-#define DQ_ABL 0      // timing ablations (results wrong by design): 2 no epilogue, 4 no MFMA loop
+#define DQ_ABL 0      // timing ablations (results wrong by design): 2 no epilogue, 4 no MFMA loop, 8 epilogue without its stores, 16 without its statistics, 32 without the pre-issued DMA
 #endif
 
 constexpr int DQ_THREADS = 512;
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(DQ_THREADS) void conv_dnq_kernel(ConvArgs a) {
     const int NKC = a.nkc;                                   // 32-channel chunks of Cin; a stage = (chunk, phase)
     const int Cin = a.cin0;
     const int tiles_per_img = a.tiles_x * a.tiles_y;
-    PersistCursor cursor(a.tiles_x, a.tiles_y, a.nimg, C / NT, 4 * NKC);          // stage index within an item = kc * 4 + phase
+    PersistCursor cursor(a.tiles_x, a.tiles_y, a.nimg, C / NT, 4 * NKC);          // stage index within an item = phase * NKC + kc (PHASE-major: below)
     const int n_items = cursor.my_items, S = cursor.S;
     if (S == 0) return;
 
@@ -136,10 +139,10 @@ __global__ __launch_bounds__(DQ_THREADS) void conv_dnq_kernel(ConvArgs a) {
     // the pieces of stage `st` (phase PH) for buffer pair b, in issue order: tile pieces 4w .. 4w + 3, the wave's slab pieces (taps of the
     // phase: 1 / 2 / 2 / 4 x 8 KB = 8 .. 32 pieces over the eight waves), tile piece 32 + w (waves 0..3)
     auto plan_stage = [&](auto ph_tag, const PersistStage& st, int b, Plan& P) __attribute__((always_inline)) {
-        constexpr int PH = decltype(ph_tag)::value;              // == st.kc & 3
+        constexpr int PH = decltype(ph_tag)::value;              // == st.kc / NKC
         constexpr int NSL = dq_ntaps(PH);                        // slab pieces per wave: the phase's taps x 8 KB over eight waves
         const unsigned tdst = smem_lds + b * DQ_TILE_BYTES, sdst = smem_lds + DQ_W_BASE + b * DQ_SLAB_BYTES;
-        const int kc = st.kc >> 2;
+        const int kc = st.kc - PH * NKC;
         const char* base = reinterpret_cast<const char*>(a.in0) + (size_t)st.it.img * a.in_rows * a.Win * (2 * Cin) + kc * 64;
         const unsigned delta = (unsigned)((PH >> 1) * a.Win + (PH & 1)) * (unsigned)(2 * Cin);
         const unsigned okp = mok >> (PH * 5);
@@ -216,13 +219,17 @@ __global__ __launch_bounds__(DQ_THREADS) void conv_dnq_kernel(ConvArgs a) {
         }
         // one stage: phase PH of a chunk on buffer pair PH & 1 (an item's stages start on pair 0: four per chunk) while the next stage's
         // pieces land in the other pair; NS = 2 * taps k-steps of 4 weight fragments x 2 pixel rows, fragments rotating as in conv_pk.hip
-        auto stage = [&](auto ph_tag) __attribute__((always_inline)) {
-            constexpr int PH = decltype(ph_tag)::value, BUF = PH & 1, NTAPS = dq_ntaps(PH);
+        // Stage order is PHASE-major (all chunks of phase 0, then of phase 1, ..): a phase's 32-channel chunks read neighbouring 64-byte
+        // pieces of the same 128-byte lines, and back to back the second piece is an L2 hit -- chunk-major (the phases of a chunk, then the
+        // next chunk, 8 us later) fetched every line of `down1`'s input from HBM twice (2.1 x its tensor; DMA-only time 102 us).
+        auto stage = [&](auto ph_tag, auto buf_tag, bool last_chunk) __attribute__((always_inline)) {
+            constexpr int PH = decltype(ph_tag)::value, BUF = decltype(buf_tag)::value, NTAPS = dq_ntaps(PH);
             Plan P;
             P.n = 0;
             if (stage_no + 1 < S && !pre_issued) {
                 if (cn.kc == 0) item_offsets(cn.it);
-                plan_stage(std::integral_constant<int, (PH + 1) & 3>{}, cn, BUF ^ 1, P);
+                if (last_chunk) plan_stage(std::integral_constant<int, (PH + 1) & 3>{}, cn, BUF ^ 1, P);       // the next phase's (or the next item's) first chunk
+                else plan_stage(std::integral_constant<int, PH>{}, cn, BUF ^ 1, P);
             }
             const unsigned char* ib = smem + BUF * DQ_TILE_BYTES;
             const unsigned char* wb = smem + DQ_W_BASE + BUF * DQ_SLAB_BYTES + b_off;
@@ -265,18 +272,23 @@ __global__ __launch_bounds__(DQ_THREADS) void conv_dnq_kernel(ConvArgs a) {
             pre_issued = false;
             flush_stats();
         };
+        // NKC is even (Cin = 64 / 128): a phase's chunks alternate the pairs starting on pair 0
+        auto phase = [&](auto ph_tag) __attribute__((always_inline)) {
 #pragma unroll 1
-        for (int kc = 0; kc < NKC; ++kc) {
-            stage(std::integral_constant<int, 0>{});
-            stage(std::integral_constant<int, 1>{});
-            stage(std::integral_constant<int, 2>{});
-            stage(std::integral_constant<int, 3>{});
-        }
+            for (int kc = 0; kc < NKC; kc += 2) {
+                stage(ph_tag, std::integral_constant<int, 0>{}, false);
+                stage(ph_tag, std::integral_constant<int, 1>{}, kc + 2 >= NKC);
+            }
+        };
+        phase(std::integral_constant<int, 0>{});
+        phase(std::integral_constant<int, 1>{});
+        phase(std::integral_constant<int, 2>{});
+        phase(std::integral_constant<int, 3>{});
         // ---- epilogue (conv_upq.hip): the pieces of the stage after next (the next item's stage 1: pair 1) first, then 8 passes of 8
         // pixels x 128 couts through the wave's patch, 16 stores of whole 256-B pixel runs
-        if (stage_no + 1 < S) {
+        if (stage_no + 1 < S && !(DQ_ABL & 32)) {
             Plan P;
-            plan_stage(std::integral_constant<int, 1>{}, cn, 1, P);
+            plan_stage(std::integral_constant<int, 0>{}, cn, 1, P);       // the next item's stage 1 = phase 0, chunk 1
 #pragma unroll
             for (int i = 0; i < 10; ++i) if (i < P.n) dq_glds16(P.src[i], P.dst[i]);
             pre_issued = true;
@@ -340,6 +352,7 @@ __global__ __launch_bounds__(DQ_THREADS) void conv_dnq_kernel(ConvArgs a) {
                         const u32x4_t v = *reinterpret_cast<const u32x4_t*>(patch + p * PITCH + ((cc_r ^ p) << 4));
                         const unsigned w[4] = {v.x, v.y, v.z, v.w};
                         float s1 = 0.f, q1 = 0.f;
+                        if constexpr (!(DQ_ABL & 16))
 #pragma unroll
                         for (int d = 0; d < 4; ++d) {
                             const bf16x2_t bv = __builtin_bit_cast(bf16x2_t, w[d]);
@@ -348,7 +361,8 @@ __global__ __launch_bounds__(DQ_THREADS) void conv_dnq_kernel(ConvArgs a) {
                         }
                         const bool ok = trow[m] && tcol0 + 8 * e + 4 * k < a.Wout;
                         ssum += ok ? s1 : 0.f; qsum += ok ? q1 : 0.f;
-                        __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ok ? toffs[m] + (unsigned)(2 * e + k) * cstep : 0xffffffffu, 0, IRE_ST_LINE);
+                        if constexpr (DQ_ABL & 8) asm volatile("" :: "v"(v));
+                        else __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ok ? toffs[m] + (unsigned)(2 * e + k) * cstep : 0xffffffffu, 0, DQ_ST);
                     }
                 }
             // this lane's chunk cc_r over its read-backs; the other lanes with the same chunk sit 16 apart
@@ -356,6 +370,7 @@ __global__ __launch_bounds__(DQ_THREADS) void conv_dnq_kernel(ConvArgs a) {
             ssum = dq_swap32_add(ssum); qsum = dq_swap32_add(qsum);
             if (l_e < 16) *reinterpret_cast<float2*>(red + red_par * (8 * 32) + (wave * 16 + cc_r) * 2) = make_float2(ssum, qsum);
             st_img = it.img; st_tile = it.tile; st_cout0 = cout0; st_par = red_par; red_par ^= 1;
+            if constexpr (DQ_ABL & 8) { if (pre_issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }      // (no stores behind the pieces: the counted wait would let them pass)
         }
     }
     __syncthreads();                     // the last item's chunk sums
@@ -367,7 +382,7 @@ __global__ __launch_bounds__(DQ_THREADS) void conv_dnq_kernel(ConvArgs a) {
 // a.in0 = full-res input [img][in_rows][Win][Cin] (a.Hin, a.Win full-res), a.out [img][Hout][Wout][cout] at half resolution;
 // a.tiles_x / tiles_y = 16 x 32 OUTPUT tiles, a.nkc = Cin / 32, a.nblocks = cout / 128, a.w = d_wdq, a.zeros; a.stats = partials [img][tile][8][2].
 void conv_dnq_launch(const ConvArgs& a, hipStream_t stream) {
-    if ((a.cout != 128 && a.cout != 256) || a.cin0 % 32 || a.nkc != a.cin0 / 32 || a.nblocks != a.cout / DQ_NT || !a.w || !a.zeros)
+    if ((a.cout != 128 && a.cout != 256) || a.cin0 % 64 || a.nkc != a.cin0 / 32 || a.nblocks != a.cout / DQ_NT || !a.w || !a.zeros)
         fail(IRE_ERR_INTERNAL, "internal: conv_dnq arguments");
     const int items = a.tiles_x * a.tiles_y * a.nimg * a.nblocks;
     const int cus = persistent_grid_cus();

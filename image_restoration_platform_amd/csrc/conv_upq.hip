@@ -37,6 +37,9 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
+#ifndef UQ_ST
+#define UQ_ST IRE_ST_LINE   // cache policy of the output stores (conv_mfma.hpp): build-time A/B
+#endif
 #ifndef UQ_ABL
 #define UQ_ABL 0      // timing ablations (results wrong by design): 1 no skip stages, 2 no epilogue, 4 no MFMA loop, 8 no tile DMA, 16 no slab DMA, 64 the k-loop twice
 #endif
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(UQ_THREADS) void conv_upq_kernel(ConvArgs a) {
                         }
                         const bool ok = trow[m] && lcol0 + 8 * e + 4 * k < a.Win;
                         ssum += ok ? s1 : 0.f; qsum += ok ? q1 : 0.f;
-                        __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ok ? toffs[m] + (unsigned)(2 * e + k) * cstep : 0xffffffffu, 0, IRE_ST_LINE);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ok ? toffs[m] + (unsigned)(2 * e + k) * cstep : 0xffffffffu, 0, UQ_ST);
                     }
                 }
             // this lane's chunk cc_r over its read-backs; the other lanes with the same chunk sit 16 apart
