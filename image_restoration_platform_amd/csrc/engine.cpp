@@ -1000,8 +1000,7 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     const bool up_fused = up_sub && op.in1 != BUF_NONE;                     // composed with the 1x1 `fuse` (build_program)
     // cout = 128: parity-major items with all 128 couts (conv_upq.hip); four partial rows per low-res tile (fp8 engines too: their `up` and
     // `down` convs stay bf16).  The cout = 64 level stays on conv_up.hip: its row-parity form of this kernel measured 278 us against 241
-    // (profiles/r04_experiments.md).  (fp8 engines and every
-    // other level: conv_up.hip.)  A function of the layer only: batch / strip invariance holds.
+    // (profiles/r04_experiments.md).  A function of the layer only: batch / strip invariance holds.
     const bool up_q = up_fused && use_upq_ && cw.d_wuq != nullptr && cw.cout == 128 && cw.cin % 32 == 0;
     const int parts_mul = up_q ? 4 : 1;     // partial rows per low-res tile: one per item (parity)
     const bool head_rb = cw.kind == CONV_HEAD && rb_tile_h_ == kRbTileH && head_rb_ && cw.d_wp != nullptr;    // the head on the pipelined kernel
