@@ -10,18 +10,21 @@
 //   * a parity of the sub-pixel form is a 2 x 2 convolution over low-res rows Y - 1 + pa .. Y + pa, columns X - 1 + pb .. X + pb with
 //     its own pre-summed weights (conv_up.hip's header): wave w = low-res rows 2w, 2w + 1 x 128 couts = 128 accumulators, per
 //     32-channel stage 4 taps x 2 k-steps x (2 pixel + 4 weight fragments) = 48 reads per 64 MFMAs;
-//   * the 1 x 1 skip term is FOUR MORE STAGES of the same pipeline (K = 32 skip channels each, one "tap"): the item's 512 skip
-//     pixels travel by LDS-DMA like an input tile -- each skip pixel is read by exactly one item, 128 KB per item;
-//   * nothing is activated on the way in (the `up` input carries no GroupNorm), so ALL staging is LDS-DMA, issued by the eight
+//   * the 1 x 1 skip term (K = 128 skip channels = eight 16-channel k-steps) rides on the eight main stages, one k-step each: a
+//     lane's two skip pixel fragments (B layout: 16 B per lane) and the step's four weight fragments (A layout: 1 KB contiguous per
+//     load) come straight from global memory into registers at the top of a stage and feed 8 MFMAs behind its k-loop -- each skip
+//     pixel is read by exactly one item (128 KB per item).  (First cut: four more pipeline STAGES with the skip pixels by LDS-DMA like
+//     an input tile: 31 us per launch for 11 % of the MFMAs -- each such stage is a bare DMA round trip; this form: 25, ~10 us saved);
+//   * nothing is activated on the way in (the `up` input carries no GroupNorm), so ALL tile / slab staging is LDS-DMA, issued by the eight
 //     computing waves one stage ahead into the other buffer pair (tile 36 KB + slab 32 KB, two pairs): no staging registers, no
 //     vector instructions besides the addresses; zero padding = lanes outside the image fetch from a page of zeros;
 //   * epilogue: conv_pk.hip's line-coalesced form (a wave transposes 8 pixels x 128 couts at a time through a 2-KB patch of its own and
 //     stores whole 256-B pixel runs); the DMA pieces of the stage after next are issued IN FRONT of the stores and the next barrier
 //     waits for "all but the 16 youngest" operations: the 128-KB-per-CU store burst drains behind the next stage's MFMAs.
-// One barrier per stage (12 per item).  GroupNorm partials: one (sum, sumsq) per group per ITEM, i.e. FOUR partial rows per low-res
+// One barrier per stage (8 per item).  GroupNorm partials: one (sum, sumsq) per group per ITEM, i.e. FOUR partial rows per low-res
 // tile (index tile * 4 + parity): the engine tells the finalize so (exec_conv: stat_parts).
 // Weights: a.w = [parity][kc32][tap4][c8][128 rows, permuted like conv_w4's][8] bf16 (engine.cpp::make_up_fused d_wuq),
-// a.w1 = skip weights [ks32][c8][128][8] (d_wsq), a.bias = composed bias.  Roofline: MFMA (executed 2*4*Cin*C + 2*C*C flop per pixel).
+// a.w1 = skip weights [ks16][h][128 rows][8] (d_wsq; as bytes the same as [ks32][c8][128][8]), a.bias = composed bias.  Roofline: MFMA (executed 2*4*Cin*C + 2*C*C flop per pixel).
 #include "conv_mfma.hpp"
 #include "persist.hpp"
 
@@ -40,16 +43,18 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #ifndef UQ_ST
 #define UQ_ST IRE_ST_LINE   // cache policy of the output stores (conv_mfma.hpp): build-time A/B
 #endif
+#ifndef UQ_DMA_SPAN
+#define UQ_DMA_SPAN 32   // the next stage's DMA pieces are issued within the first UQ_DMA_SPAN / 32 of the k-loop's MFMA pairs
+#endif
 #ifndef UQ_ABL
-#define UQ_ABL 0      // timing ablations (results wrong by design): 1 no skip stages, 2 no epilogue, 4 no MFMA loop, 8 no tile DMA, 16 no slab DMA, 64 the k-loop twice
+#define UQ_ABL 0      // timing ablations (results wrong by design): 1 no skip term, 2 no epilogue, 4 no MFMA loop, 8 no tile DMA, 16 no slab DMA, 64 the k-loop twice
 #endif
 
 constexpr int UQ_THREADS = 512;
-constexpr int UQ_TH = 16, UQ_TW = 32, UQ_IH = 17, UQ_IW = 33, UQ_NT = 128, UQ_NTL = 4, UQ_NSK = UQ_NT / 32;
+constexpr int UQ_TH = 16, UQ_TW = 32, UQ_IH = 17, UQ_IW = 33, UQ_NT = 128, UQ_NTL = 4;
 constexpr int UQ_TILE_PIECES = 36;                              // 17 x 33 pixels x 64 B = 35 904 B as 1-KB DMA pieces (the last 960 B: dummy slots)
 constexpr int UQ_TILE_BYTES = UQ_TILE_PIECES * 1024;
 constexpr int UQ_SLAB_BYTES = 4 * 4 * UQ_NT * 16;               // main stage: [tap4][c8][128][8 bf16] = 32 768
-constexpr int UQ_SKSLAB_BYTES = 4 * UQ_NT * 16;                 // skip stage: [c8][128][8] = 8 192
 constexpr int UQ_W_BASE = 2 * UQ_TILE_BYTES;                    // LDS: tile[2] | slab[2] | red | bias
 constexpr int UQ_RED_BASE = UQ_W_BASE + 2 * UQ_SLAB_BYTES;
 constexpr int UQ_RED_BYTES = 2 * 8 * 16 * 2 * 4;                // [item parity][8 waves][16 chunks of 8 couts][sum, sumsq]
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(UQ_THREADS) void conv_upq_kernel(ConvArgs a) {
     const int wv = __builtin_amdgcn_readfirstlane(wave);
 
     const int NKC = a.nkc;                                   // 32-channel stages of the sub-pixel convolution (Cin / 32)
-    const int NST = NKC + ((UQ_ABL & 1) ? 0 : UQ_NSK);       // + the skip term's
+    const int NST = NKC;                                     // (the skip term's k-steps ride at the end of the main stages: below)
     const int Cin = a.cin0;
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     PersistCursor cursor(a.tiles_x, a.tiles_y, a.nimg, 4, NST);          // it.nb = output parity pa * 2 + pb
@@ -121,12 +126,13 @@ __global__ __launch_bounds__(UQ_THREADS) void conv_upq_kernel(ConvArgs a) {
     // The pieces of stage `st` for buffer pair b (its readers are behind the last barrier): sources and LDS destinations only -- the
     // caller issues them (in the prologue at once; in a stage BETWEEN the MFMA pairs of the k-loop: a DMA instruction holds the wave's
     // issue for 100+ cycles, and nine of them in front of the k-loop left the matrix pipe idle for a third of the stage).
-    // Order: tile pieces 4w .. 4w + 3, the wave's slab pieces (four, or one in a skip stage), tile piece 32 + w (waves 0..3).
+    // Order: tile pieces 4w .. 4w + 3, the wave's four slab pieces, tile piece 32 + w (waves 0..3).
     struct Plan { const void* src[10]; unsigned dst[10]; int n; };
     // a lane's byte offsets within the image, once per ITEM (main: low-res input pixel, skip: the parity's output pixel, both at
     // channel 8 c8 of stage 0); ~0u = outside the image / a dummy slot: that lane fetches from the page of zeros.  A stage's plan
     // is then base(image, stage) + offset: ~30 vector instructions in front of the k-loop instead of ~120.
-    unsigned moff[5], soff[5];
+    unsigned moff[5];
+    unsigned skoff[2];                                       // the lane's skip pixels (rows m = 0, 1) as B fragments: byte offset in the skip image at channel 8 h, ~0u outside
     auto item_offsets = [&](const PersistItem& it) __attribute__((always_inline)) {
         const int pa = it.nb >> 1, pb = it.nb & 1;
         const int Y0 = it.ty * UQ_TH, X0 = it.tx * UQ_TW;
@@ -137,46 +143,31 @@ __global__ __launch_bounds__(UQ_THREADS) void conv_upq_kernel(ConvArgs a) {
             const int ry = ybase + py, ix = xbase + px;               // ry: row relative to the first readable one
             const bool okm = py < UQ_IH && (unsigned)ry < (unsigned)a.iy_span && (unsigned)ix < (unsigned)a.Win;
             moff[d] = okm ? (unsigned)((ry + a.iy_lo + a.in_row_off) * a.Win + ix) * (unsigned)(2 * Cin) + (unsigned)(c8 * 16) : ~0u;
-            const int ly = Y0 + py, lx = X0 + px;
-            const bool oks = py < UQ_TH && px < UQ_TW && ly < a.Hin && lx < a.Win;
-            soff[d] = oks ? (unsigned)((2 * ly + pa) * a.Wout + 2 * lx + pb) * (unsigned)(2 * C) + (unsigned)(c8 * 16) : ~0u;
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int ly = Y0 + 2 * wave + m, lx = X0 + r;
+            skoff[m] = (ly < a.Hin && lx < a.Win) ? (unsigned)((2 * ly + pa) * a.Wout + 2 * lx + pb) * (unsigned)(2 * C) + (unsigned)(h * 16) : ~0u;
         }
     };
     auto plan_stage = [&](const PersistStage& st, int b, Plan& P) __attribute__((always_inline)) {
         const unsigned tdst = smem_lds + b * UQ_TILE_BYTES, sdst = smem_lds + UQ_W_BASE + b * UQ_SLAB_BYTES;
-        const bool skip = st.kc >= NKC;
+        const char* base = reinterpret_cast<const char*>(a.in0) + (size_t)st.it.img * a.in_rows * a.Win * (2 * Cin) + st.kc * 64;
         const char* tsrc[5];
-        const char* base = skip ? reinterpret_cast<const char*>(a.in1) + (size_t)st.it.img * a.Hout * a.Wout * (2 * C) + (st.kc - NKC) * 64
-                                : reinterpret_cast<const char*>(a.in0) + (size_t)st.it.img * a.in_rows * a.Win * (2 * Cin) + st.kc * 64;
 #pragma unroll
-        for (int d = 0; d < 5; ++d) {
-            const unsigned off = skip ? soff[d] : moff[d];
-            tsrc[d] = off != ~0u ? base + off : zeros;
-        }
+        for (int d = 0; d < 5; ++d) tsrc[d] = moff[d] != ~0u ? base + moff[d] : zeros;
 #pragma unroll
         for (int d = 0; d < 4; ++d) { P.src[d] = tsrc[d]; P.dst[d] = tdst + (4 * wv + d) * 1024; }
-        int n = 4;
-        if (!skip) {
-            const unsigned char* ws = reinterpret_cast<const unsigned char*>(a.w) + ((size_t)st.it.nb * NKC + st.kc) * UQ_SLAB_BYTES;
+        const unsigned char* ws = reinterpret_cast<const unsigned char*>(a.w) + ((size_t)st.it.nb * NKC + st.kc) * UQ_SLAB_BYTES;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) { const int piece = wv + 8 * d; P.src[4 + d] = ws + (size_t)(piece * 64 + lane) * 16; P.dst[4 + d] = sdst + piece * 1024; }
-            P.src[8] = tsrc[4]; P.dst[8] = tdst + (32 + (wv & 3)) * 1024;
-            P.src[9] = tsrc[4]; P.dst[9] = P.dst[8];
-            n = wv < 4 ? 9 : 8;
-        } else {
-            const unsigned char* ws = reinterpret_cast<const unsigned char*>(a.w1) + (size_t)(st.kc - NKC) * UQ_SKSLAB_BYTES;
-            P.src[4] = ws + (size_t)(wv * 64 + lane) * 16; P.dst[4] = sdst + wv * 1024;
-            P.src[5] = tsrc[4]; P.dst[5] = tdst + (32 + (wv & 3)) * 1024;
-#pragma unroll
-            for (int d = 6; d < 10; ++d) { P.src[d] = tsrc[4]; P.dst[d] = P.dst[5]; }
-            n = wv < 4 ? 6 : 5;
-        }
-        P.n = n;
+        for (int d = 0; d < 4; ++d) { const int piece = wv + 8 * d; P.src[4 + d] = ws + (size_t)(piece * 64 + lane) * 16; P.dst[4 + d] = sdst + piece * 1024; }
+        P.src[8] = tsrc[4]; P.dst[8] = tdst + (32 + (wv & 3)) * 1024;
+        P.src[9] = tsrc[4]; P.dst[9] = P.dst[8];
+        P.n = wv < 4 ? 9 : 8;
     };
 
     // ---- fragment addressing.  Pixel fragment (row m, tap (dy, dx), k-step k): window pixel p = (2w + m + dy) 33 + r + dx, chunk
-    // c8 = 2k + h: byte (p * 4 + (c8 ^ ((p >> 2) & 3))) * 16 -- k toggles bit 5.  The skip stages read tap (0, 0) of the same window
-    // (their tile is staged at window rows 0..15, columns 0..31).  Weight fragment (tap, k, rows 32 j + r): ((tap*4 + 2k + h) 128 + 32 j + r) 16.
+    // c8 = 2k + h: byte (p * 4 + (c8 ^ ((p >> 2) & 3))) * 16 -- k toggles bit 5.  Weight fragment (tap, k, rows 32 j + r): ((tap*4 + 2k + h) 128 + 32 j + r) 16.
     // The eight pixel-fragment addresses carry the tile base of the buffer pair in use (they step by +- one tile per stage).
     int a_off[2][4];
 #pragma unroll
@@ -239,6 +230,21 @@ __global__ __launch_bounds__(UQ_THREADS) void conv_upq_kernel(ConvArgs a) {
         // one pipeline stage: NTAPS taps of 2 k-steps on the pair in use while the next stage's tile and slab land in the other
         // (ONE k-loop per loop body: two variants under a branch make the accumulators PHIs that hipcc copies and spills)
         auto stage = [&](auto ntaps_tag) __attribute__((always_inline)) {
+            // the 1 x 1 skip term, one 16-channel k-step per main stage (Cin / 32 == C / 16 stages): this lane's two skip pixel fragments
+            // (B layout: 16 B of pixel (2 (Y0 + 2w + m) + pa, 2 (X0 + r) + pb), channels 16 ks + 8 h) and the four weight fragments (A layout:
+            // rows 32 j + r of [ks][h][128][8]: 1 KB contiguous per load) come STRAIGHT FROM GLOBAL MEMORY into registers at the top of the
+            // stage and are used behind its k-loop -- the separate skip stages (a DMA round trip for 16 MFMAs each) are gone
+            u32x4_t skp[2], skw[NTL];
+            if constexpr (!(UQ_ABL & 1)) {
+                const int ks = cs.kc;
+                char* sbase = const_cast<char*>(reinterpret_cast<const char*>(a.in1)) + (size_t)cs.it.img * a.Hout * a.Wout * (2 * C) + ks * 32;
+                const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(sbase, 0, a.Hout * a.Wout * (2 * C) - ks * 32, 0x00020000);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) skp[m] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, skoff[m], 0, 0);      // ~0u: out of range reads as zero
+                const char* wsk = reinterpret_cast<const char*>(a.w1) + ((size_t)(ks * 2 + h) * NT + r) * 16;
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) skw[j] = *reinterpret_cast<const u32x4_t*>(wsk + j * 512);
+            }
             Plan P;
             P.n = 0;
             if (stage_no + 1 < S && !pre_issued) {
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(UQ_THREADS) void conv_upq_kernel(ConvArgs a) {
                         // the next stage's DMA pieces, spread over the k-loop: piece i rides in front of MFMA pair (i NG) / 10
 #pragma unroll
                         for (int i = 0; i < 10; ++i)
-                            if ((i * NG) / 10 == g && i < P.n && !(((UQ_ABL & 8) && (i < 4 || i >= P.n - (wv < 4 ? 1 : 0))) || ((UQ_ABL & 16) && i >= 4 && i < P.n - (wv < 4 ? 1 : 0)))) uq_glds16(P.src[i], P.dst[i]);
+                            if ((i * (NG * UQ_DMA_SPAN / 32)) / 10 == g && i < P.n && !(((UQ_ABL & 8) && (i < 4 || i >= P.n - (wv < 4 ? 1 : 0))) || ((UQ_ABL & 16) && i >= 4 && i < P.n - (wv < 4 ? 1 : 0)))) uq_glds16(P.src[i], P.dst[i]);
                         if (g + 1 < NG) bq[(g + 1) & 1] = rd_b((g + 1) / NTL, (g + 1) % NTL);
                         if (st + 1 < NS && j == 1) aq[(st + 1) & 1][0] = rd_a(st + 1, 0);
                         if (st + 1 < NS && j == 2) aq[(st + 1) & 1][1] = rd_a(st + 1, 1);
@@ -284,6 +290,13 @@ __global__ __launch_bounds__(UQ_THREADS) void conv_upq_kernel(ConvArgs a) {
             if constexpr (UQ_ABL & 4) {
 #pragma unroll
                 for (int i = 0; i < 10; ++i) if (i < P.n) uq_glds16(P.src[i], P.dst[i]);
+            }
+            if constexpr (!(UQ_ABL & 1) && !(UQ_ABL & 4)) {
+#pragma unroll
+                for (int j = 0; j < NTL; ++j)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, skw[j]), __builtin_bit_cast(bf16x8_t, skp[m]), acc[m][j], 0, 0, 0);
             }
             {   // the fragment addresses move to the other tile
                 const int step = buf ? -UQ_TILE_BYTES : UQ_TILE_BYTES;
@@ -302,8 +315,6 @@ __global__ __launch_bounds__(UQ_THREADS) void conv_upq_kernel(ConvArgs a) {
         };
 #pragma unroll 1
         for (int kc = 0; kc < NKC; ++kc) stage(std::integral_constant<int, 4>{});
-#pragma unroll 1
-        for (int kc = NKC; kc < NST; ++kc) stage(std::integral_constant<int, 1>{});
         // ---- epilogue: conv_pk.hip's line-coalesced form in 8-pixel passes through a 2-KB patch of the wave's own, so that both buffers of
         // the other pair are free NOW: the pieces of the stage after next (the next item's stage 1) are issued first, the stores behind them.
         if (stage_no + 1 < S) {
@@ -403,7 +414,7 @@ __global__ __launch_bounds__(UQ_THREADS) void conv_upq_kernel(ConvArgs a) {
 // a.in0 = low-res input [img][in_rows][Win][Cin], a.in1 = skip [img][Hout][Wout][128] at its first real row, a.out likewise;
 // a.tiles_x / tiles_y = 16 x 32 LOW-res tiles, a.nkc = Cin / 32, a.nblocks = 4 (parities); a.stats = partials [img][tile * 4 + parity][8][2].
 void conv_upq_launch(const ConvArgs& a, hipStream_t stream) {
-    if (a.cout != UQ_NT || a.cin1 != UQ_NT || a.cin0 % 32 || a.nkc != a.cin0 / 32 || a.nblocks != 4 || !a.w || !a.w1 || !a.in1 || !a.zeros ||
+    if (a.cout != UQ_NT || a.cin1 != UQ_NT || a.cin0 != 2 * UQ_NT || a.nkc != a.cin0 / 32 || a.nblocks != 4 || !a.w || !a.w1 || !a.in1 || !a.zeros ||
         a.Hout != 2 * a.Hin || a.Wout != 2 * a.Win)
         fail(IRE_ERR_INTERNAL, "internal: conv_upq arguments");
     const int items = a.tiles_x * a.tiles_y * a.nimg * 4;
