@@ -78,23 +78,21 @@ template <int C> struct PcCfg {
     static constexpr int NBLK = C / NT;                                         // n-blocks (items per tile)
     static constexpr int NKC = C / 32;                                          // 32-channel stages per item
     static constexpr int NTL = NT / 32;                                         // 32-cout n-tiles per wave
-    static constexpr bool STREAM = C > 64;                                      // weight slabs streamed per stage (two LDS slots) instead of resident
     static constexpr int W_STAGE = 36 * NT * 16;                                // [kk = tap*4 + c8][NT rows] x 16 B per stage
     static constexpr int W_STAGE_CHUNKS = 36 * NT;
-    static constexpr int W_LDS = (STREAM ? 2 : NKC) * W_STAGE;
+    static constexpr int W_LDS = NKC * W_STAGE;                                 // the layer's weights stay in LDS for the whole kernel
     static constexpr int W_OFF = 2 * C3_IN_BYTES;
     static constexpr int BIAS_OFF = W_OFF + W_LDS;
     static constexpr int NCC = NT / 8;                                          // 16-B chunks of an item's couts per pixel
     static constexpr int RED_OFF = BIAS_OFF + C * 4;                            // 2 x [8 waves][NCC chunks][sA, qA, sB, qB]
     static constexpr int RED_HALF = 8 * NCC * 4;                                // floats
-    static constexpr int COEF_IMGS = C == 32 ? 64 : C == 64 ? 8 : 2;            // images whose (A, B) the LDS table holds
+    static constexpr int COEF_IMGS = C == 32 ? 64 : 8;                          // images whose (A, B) the LDS table holds
     static constexpr int COEF_OFF = RED_OFF + 2 * RED_HALF * 4;
     static constexpr int HEAD_OFF = COEF_OFF + COEF_IMGS * C * 2 * 4;           // head: [8 waves][in | out][2 rows][96 B]
     static constexpr int PATCH_OFF = HEAD_OFF + (C == 32 ? 8 * 2 * 2 * 96 : 0);   // C = 32: [8 waves][32 pixels x 64 B] transpose patches of the line-coalesced epilogue
     static constexpr int CNT_OFF = PATCH_OFF + (C == 32 ? 8 * 2048 : 0);          // C = 64: the consumers' rendezvous counter (16 B)
     static constexpr int LDS = CNT_OFF + (C == 64 ? 16 : 0);
     static_assert(LDS <= 160 * 1024, "LDS");
-    static_assert(!STREAM || W_STAGE_CHUNKS == 9 * C3_PROD, "a producer thread streams 9 weight chunks per stage");
 };
 
 __device__ __forceinline__ unsigned c3_pack(float a, float b) {
@@ -129,7 +127,6 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
     constexpr int PROD = pc_prod(C, HEAD), THREADS = C3_CONS + PROD;
     constexpr int P_ITERS = (C3_IN_CHUNKS + PROD - 1) / PROD;        // chunks per producer thread and stage: 10 or 5 (P_ITERS * PROD * 16 == C3_IN_BYTES either way)
     static_assert(P_ITERS * PROD * 16 == C3_IN_BYTES, "tile slots");
-    static_assert(!K::STREAM || PROD == C3_PROD, "the streamed-weights form is written for four producer waves");
     constexpr int NKC = K::NKC, NTL = K::NTL, NCC = K::NCC, NT = K::NT;
     static_assert(!HEAD || C == 32, "the head is a C = 32 layer");
     __shared__ __attribute__((aligned(16))) unsigned char smem[K::LDS];
@@ -167,10 +164,10 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
     tl(0);
     {   // the weights (all of them, or the first slab of the streamed form) leave for LDS by DMA BEFORE the folded GroupNorm finalize: their
         // fetch rides under its reduction (the finalize's scratch is the first 8 KB of the tile area, the weights sit behind both tiles)
-        const unsigned char* ws = reinterpret_cast<const unsigned char*>(a.w) + (K::STREAM ? (size_t)cursor.cur.it.nb * NKC * K::W_STAGE : 0);
+        const unsigned char* ws = reinterpret_cast<const unsigned char*>(a.w);
         const unsigned wl = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + K::W_OFF;
-        constexpr int PIECES = (K::STREAM ? 1 : NKC) * K::W_STAGE_CHUNKS / 64;                 // 1-KB pieces: 18 (C = 32), 72 (C = 64), 36 (streamed)
-        static_assert(((K::STREAM ? 1 : NKC) * K::W_STAGE_CHUNKS) % 64 == 0, "whole wave-instructions");
+        constexpr int PIECES = NKC * K::W_STAGE_CHUNKS / 64;                 // 1-KB pieces: 18 (C = 32), 72 (C = 64)
+        static_assert((NKC * K::W_STAGE_CHUNKS) % 64 == 0, "whole wave-instructions");
         const int wv = __builtin_amdgcn_readfirstlane(wave);
         for (int p = wv; p < PIECES; p += THREADS / 64) c3_glds16(ws + ((size_t)p * 64 + lane) * 16, wl + p * 1024);
     }
@@ -247,32 +244,8 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
         // as soon as a pair has been transformed the same registers are reloaded with the NEXT stage's pair, so every load has
         // most of a stage's time to land and the first pair of the next transform is the oldest request.  Straight-line code on
         // purpose: with the reloads under a branch hipcc loses the order of the pending loads at the join and waits for all.
-        // streamed weights (C >= 128): this thread's 9 chunks of the slab of stage `ls` travel global -> registers -> LDS slot beside
-        // the tile, two chunks per transform pair through a ring of three register sets (requested two pairs before they are
-        // written: an L2 round trip), all compiler-counted loads in the same straight line as the input stream
-        uint4 wr0a, wr0b, wr1a, wr1b, wr2a, wr2b;                               // (named registers: an indexed or address-taken array goes to scratch)
-        const uint4* wsrc = nullptr;
-        auto w_issue = [&](auto p_tag) __attribute__((always_inline)) {          // chunks 2p, 2p + 1 (chunk k = tp + 256 k; k = 9 does not exist)
-            if constexpr (K::STREAM) {
-                constexpr int p = decltype(p_tag)::value;
-                const uint4 va = wsrc[tp + (2 * p) * C3_PROD];
-                uint4 vb = va;
-                if constexpr (2 * p + 1 < 9) vb = wsrc[tp + (2 * p + 1) * C3_PROD];
-                if constexpr (p % 3 == 0) { wr0a = va; wr0b = vb; } else if constexpr (p % 3 == 1) { wr1a = va; wr1b = vb; } else { wr2a = va; wr2b = vb; }
-            }
-        };
-        auto w_store = [&](auto p_tag, unsigned char* wslot) __attribute__((always_inline)) {
-            if constexpr (K::STREAM) {
-                constexpr int p = decltype(p_tag)::value;
-                uint4 va, vb;
-                if constexpr (p % 3 == 0) { va = wr0a; vb = wr0b; } else if constexpr (p % 3 == 1) { va = wr1a; vb = wr1b; } else { va = wr2a; vb = wr2b; }
-                reinterpret_cast<uint4*>(wslot)[tp + (2 * p) * C3_PROD] = va;
-                if constexpr (2 * p + 1 < 9) reinterpret_cast<uint4*>(wslot)[tp + (2 * p + 1) * C3_PROD] = vb;
-            }
-        };
-        auto transform_stage_v = [&](unsigned char* tile, unsigned char* wslot, auto interior_tag) __attribute__((always_inline)) {
+        auto transform_stage_v = [&](unsigned char* tile, auto interior_tag) __attribute__((always_inline)) {
             constexpr bool INTERIOR = decltype(interior_tag)::value;
-            w_issue(std::integral_constant<int, 0>{}); w_issue(std::integral_constant<int, 1>{});
             auto pair = [&](auto pp_tag) __attribute__((always_inline)) {
                 constexpr int pp_ = decltype(pp_tag)::value, i = 2 * pp_;
                 constexpr int NCH = i + 1 < P_ITERS ? 2 : 1;              // chunks in this group (the last group of an odd P_ITERS is a single chunk)
@@ -346,8 +319,6 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
                 }
                 load_chunk(i);
                 if constexpr (NCH == 2) load_chunk(i + 1);
-                w_store(pp_tag, wslot);
-                if constexpr (pp_ + 2 < 5) w_issue(std::integral_constant<int, pp_ + 2>{});
                 __builtin_amdgcn_sched_barrier(0);
             };
             pair(std::integral_constant<int, 0>{}); pair(std::integral_constant<int, 1>{}); pair(std::integral_constant<int, 2>{});
@@ -359,32 +330,27 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
             const int q = tp + (P_ITERS - 1) * PROD;
             past_last = (q >> 2) >= C3_IH * C3_IW ? (1u << (P_ITERS - 1)) : 0u;
         }
-        auto transform_stage = [&](unsigned char* tile, unsigned char* wslot) __attribute__((always_inline)) {
+        auto transform_stage = [&](unsigned char* tile) __attribute__((always_inline)) {
             if constexpr (C3_INTERIOR) {
-                if (__builtin_amdgcn_ballot_w64((okbits | past_last) != (1u << P_ITERS) - 1u) == 0) { transform_stage_v(tile, wslot, std::true_type{}); return; }
+                if (__builtin_amdgcn_ballot_w64((okbits | past_last) != (1u << P_ITERS) - 1u) == 0) { transform_stage_v(tile, std::true_type{}); return; }
             }
-            transform_stage_v(tile, wslot, std::false_type{});
+            transform_stage_v(tile, std::false_type{});
         };
         // stage 0 -> R; then every transform reloads R with the stage after (past the last stage the cursor stays on it: a
         // redundant reload of rows that are never used).  `ps` = the stage whose rows are in R = the stage being produced.
-        auto slab_of = [&](const PersistStage& st) -> const uint4* {
-            return reinterpret_cast<const uint4*>(a.w) + ((size_t)st.it.nb * NKC + st.kc) * K::W_STAGE_CHUNKS;
-        };
 #pragma unroll
         for (int i = 0; i < P_ITERS; ++i) load_chunk(i);
         load_coeffs(ls);
-        wsrc = slab_of(ls);                                     // (slot 0 already holds it: the kernel prologue; written again, same bytes)
         ls = cursor.next();
-        transform_stage(smem, smem + K::W_OFF);
+        transform_stage(smem);
         c3_barrier();                                           // tile (and slab) of stage 0 are staged
         for (int t = 0; t < n_stages; ++t) {
             // tile / slab of stage t + 1 (for t + 1 == n_stages: the last stage again, into the slots nobody reads any more)
             stamp_item = t / NKC;
             stamp(3 * (t % NKC) + 0);
             load_coeffs(ls);
-            wsrc = slab_of(ls);
             ls = cursor.next();
-            transform_stage(smem + ((t + 1) & 1) * C3_IN_BYTES, smem + K::W_OFF + ((t + 1) & 1) * K::W_STAGE);   // the consumers finished reading these slots before the last barrier
+            transform_stage(smem + ((t + 1) & 1) * C3_IN_BYTES);   // the consumers finished reading this slot before the last barrier
             stamp(3 * (t % NKC) + 1);
             c3_barrier();
             stamp(3 * (t % NKC) + 2);
@@ -460,7 +426,7 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
     // workgroup barrier: the producers must not wait here).  Why it pays at C = 64 and not at C = 32: here the item's stores sit on
     // the critical path -- stamps (profiles/r03_experiments.md): the eight consumer waves issue their 64 partial-line stores
     // together, ~66 addresser cycles each = 4 200 of the epilogue's 5 000 ticks, and the producers wait 4 000 ticks at the barrier.
-    constexpr bool TEPI64 = C3_TEPI64 && C == 64 && !HEAD && !K::STREAM;
+    constexpr bool TEPI64 = C3_TEPI64 && C == 64 && !HEAD;
     unsigned toffs[2];            // byte offset of (read-back pixel lane >> 2 of row m, chunk lane & 3) in the output image
     bool trow[2];
     int tcol = 0;
@@ -568,7 +534,7 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
             constexpr int PAR = decltype(par_tag)::value;
             const int par = PAR >= 0 ? PAR : (stage_no & 1);
             const unsigned char* ib = smem + par * C3_IN_BYTES;
-            const unsigned char* wk = wb + (K::STREAM ? par : kc) * K::W_STAGE;
+            const unsigned char* wk = wb + kc * K::W_STAGE;
             bf16x8_t af[2][2], bf[2][NTL];
             auto read_k = [&](int g, bf16x8_t (&pa)[2], bf16x8_t (&pw)[NTL]) __attribute__((always_inline)) {
                 const int tap = g >> 1, cp = g & 1;
@@ -864,15 +830,17 @@ __global__ __launch_bounds__(C3_CONS + pc_prod(C, HEAD)) void conv_pc_kernel(Con
 
 }  // namespace
 
-// C = 32 .. 256 ResBlock convs with the activation applied while staging (a.ab required), and the head: a.w = permuted-row slabs
-// [n-block of NT = min(C, 64) couts][k-chunk][kk = tap*4 + c8][NT rows][8] (engine.cpp::make_conv d_wp), 16x32 tiles, a.stats =
-// partials [img][tile][8][2] (not for the head).  The producers' coefficient table holds 64 / 8 / 2 / 2 images (C = 32 / 64 /
-// 128 / 256): conv_pc_fits() tells the engine whether every workgroup of a launch stays within it.
+// C = 32 / 64 ResBlock convs with the activation applied while staging (a.ab required), and the head: a.w = permuted-row slabs
+// [k-chunk][kk = tap*4 + c8][C rows][8] (engine.cpp::make_conv d_wp), 16x32 tiles, a.stats = partials [img][tile][8][2] (not for the
+// head).  The producers' coefficient table holds 64 / 8 images (C = 32 / 64): conv_pc_fits() tells the engine whether every
+// workgroup of a launch stays within it.  (The C >= 128 form of this kernel -- 64-cout items, weight slabs streamed by the producers,
+// IRE_PC=7 -- lost to conv_w4 in round 2 and was superseded by conv_pk.hip in round 4: removed.)
 bool conv_pc_fits(int C, int tiles_per_img, int nimg) {
-    const int imgs = C == 32 ? PcCfg<32>::COEF_IMGS : C == 64 ? PcCfg<64>::COEF_IMGS : PcCfg<128>::COEF_IMGS;
+    if (C != 32 && C != 64) return false;
+    const int imgs = C == 32 ? PcCfg<32>::COEF_IMGS : PcCfg<64>::COEF_IMGS;
     if (nimg <= imgs) return true;
     // the workgroups of XCD group x walk items [items x / X, items (x + 1) / X) (persist.hpp): images spanned by a range
-    const int nblk = C < 64 ? 1 : C / 64;
+    const int nblk = 1;
     const long long ipi = (long long)tiles_per_img * nblk, items = ipi * nimg;
     const int cus = persistent_grid_cus();
     const long long G = items < cus ? items : cus, X = G < 8 ? G : 8;
@@ -885,7 +853,7 @@ bool conv_pc_fits(int C, int tiles_per_img, int nimg) {
 
 void conv_pc_launch(bool resid, bool head, const ConvArgs& a, hipStream_t stream) {
     const int C = a.cout;
-    if ((C != 32 && C != 64 && C != 128 && C != 256) || a.cin0 != C || a.nkc != C / 32 || a.nblocks != (C < 64 ? 1 : C / 64) || !a.ab)
+    if ((C != 32 && C != 64) || a.cin0 != C || a.nkc != C / 32 || a.nblocks != 1 || !a.ab)
         fail(IRE_ERR_INTERNAL, "internal: conv_pc arguments");
     if (head ? (C != 32 || !a.u8_in || !a.u8_out) : !a.stats) fail(IRE_ERR_INTERNAL, "internal: conv_pc arguments");
     if (!conv_pc_fits(C, a.tiles_x * a.tiles_y, a.nimg)) fail(IRE_ERR_INTERNAL, "internal: conv_pc batch");
@@ -895,9 +863,7 @@ void conv_pc_launch(bool resid, bool head, const ConvArgs& a, hipStream_t stream
 #define PC_GO(CC, RS, HD) hipLaunchKernelGGL((conv_pc_kernel<CC, RS, HD>), dim3(grid), dim3(C3_CONS + pc_prod(CC, HD)), 0, stream, a)
     if (head) PC_GO(32, false, true);
     else if (C == 32) { if (resid) PC_GO(32, true, false); else PC_GO(32, false, false); }
-    else if (C == 64) { if (resid) PC_GO(64, true, false); else PC_GO(64, false, false); }
-    else if (C == 128) { if (resid) PC_GO(128, true, false); else PC_GO(128, false, false); }
-    else { if (resid) PC_GO(256, true, false); else PC_GO(256, false, false); }
+    else { if (resid) PC_GO(64, true, false); else PC_GO(64, false, false); }
 #undef PC_GO
     IRE_HIP(hipGetLastError());
 }

@@ -1058,12 +1058,7 @@ void Engine::exec_conv(Run& R, const Op& op, const Geo& g) {
     }
     prof_begin(fam, R.stream, flops, bytes);
     const char* kname = "conv_mfma";       // which kernel takes this launch (the branches below)
-    const bool pc_hi = rb && rb_tile_h_ == kRbTileH && (pc_split_ & 4) && cw.cout >= 128 && cw.cin == cw.cout && a.ab != nullptr && cw.d_wp != nullptr &&
-                       cw.d_w8 == nullptr && conv_pc_fits(cw.cout, a.tiles_x * a.tiles_y, g.nimg);       // (fp8 engines keep conv_f8 / conv_w4)
-    if (pc_hi) {
-        a.w = cw.d_wp;
-        conv_pc_launch(cw.kind == CONV_RB2, false, a, R.stream); kname = "conv_pc";
-    } else if (w4 && fp8_mx_ && cw.d_w8x != nullptr && a.ab != nullptr) {   // IRE_PRECISION_FP8: the 2x-rate block-scaled fp8 MFMA
+    if (w4 && fp8_mx_ && cw.d_w8x != nullptr && a.ab != nullptr) {   // IRE_PRECISION_FP8: the 2x-rate block-scaled fp8 MFMA
         a.fp8 = 1; a.w = reinterpret_cast<const unsigned short*>(cw.d_w8x); a.bias = cw.d_bias8; a.oscale = cw.d_oscale;
         a.nkc = cw.cin / 32; a.nblocks = cw.cout / 128;
         conv_f8_launch(cw.kind == CONV_RB2, a, R.stream); kname = "conv_f8";

@@ -231,7 +231,7 @@ private:
     int fp8_mx_ = 1;              // fp8: the block-scaled K = 64 MFMA (conv_f8.hip); IRE_FP8_MX=0: the same-rate 32x32x16 fp8 form in conv_w4.hip
     int down_rb_ = 1;             // stride-2 `down` convs on conv_down.hip's pipelined phase kernel (IRE_DOWN_RB=0: the v1 kernel)
     int head_rb_ = 1;             // the 32 -> 3 head conv on conv_rb.hip's pipelined kernel (IRE_HEAD_RB=0: the v1 kernel)
-    int pc_split_ = 3;            // producer / consumer workgroups (conv_pc.hip): bit 0 = C = 32 ResBlock convs + head, bit 1 = C = 64, bit 2 = C >= 128 on 64-cout items (slower than conv_w4.hip: 205 vs 190 us per launch, off by default); IRE_PC=0: conv_rb.hip / conv_w4.hip
+    int pc_split_ = 3;            // producer / consumer workgroups (conv_pc.hip): bit 0 = C = 32 ResBlock convs + head, bit 1 = C = 64; IRE_PC=0: conv_rb.hip
     int gn_fold_ = 1;             // GroupNorm finalize inside the consuming conv's prologue (gn_fold.hpp); IRE_GN_FOLD=0: 33 gn_finalize launches per step
     int stem_rb_ = 1;             // the stem on its own kernel (conv_stem.hip); IRE_STEM_RB=0: the v1 template
     int up_fuse_ = 1;             // `up` + 1x1 `fuse` as ONE composed convolution with the skip term in conv_up.hip's epilogue (IRE_UP_FUSE=0: two kernels)

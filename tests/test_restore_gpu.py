@@ -92,7 +92,7 @@ def test_seeded_random_shapes_vs_fp32_oracle(engine, weights0):
 
 
 @pytest.mark.parametrize("env", [{"IRE_W4": "0"}, {"IRE_CONV_V1": "1"}, {"IRE_UP_RB_MINC": "64"},
-                                 {"IRE_UP_SUBPIX": "0"}, {"IRE_UP_FUSE": "0"}, {"IRE_GN_FOLD": "0"}, {"IRE_PC": "0"}, {"IRE_PC": "1"}, {"IRE_PC": "7"}, {"IRE_PC": "3"}, {"IRE_PC": "0", "IRE_GN_FOLD": "0"}, {"IRE_DOWN_RB": "0", "IRE_HEAD_RB": "0"}, {"IRE_STEM_RB": "0"},
+                                 {"IRE_UP_SUBPIX": "0"}, {"IRE_UP_FUSE": "0"}, {"IRE_GN_FOLD": "0"}, {"IRE_PC": "0"}, {"IRE_PC": "1"}, {"IRE_PC": "3"}, {"IRE_PC": "0", "IRE_GN_FOLD": "0"}, {"IRE_DOWN_RB": "0", "IRE_HEAD_RB": "0"}, {"IRE_STEM_RB": "0"},
                                  {"IRE_W4_SPLIT": "0"}, {"IRE_PK": "0"}, {"IRE_PK": "2"}, {"IRE_UPQ": "0"}, {"IRE_DNQ": "0"}])
 def test_alternate_kernel_schedules_agree(engine, weights0, env, monkeypatch):
     """Every A/B switch of the engine (conv_rb instead of conv_w4 at C >= 128, the v1 conv schedule, the
